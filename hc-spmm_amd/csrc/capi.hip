@@ -1,0 +1,113 @@
+// capi.hip -- C-ABI entry points that enqueue device work (see include/hcspmm.h).
+//
+// hcspmm_forward replaces the reference launchers spmm_forward_plus / _more / _fixed32 / _fixed64
+// (hybrid_kernel/hybrid_all_kernel.cu:410-594) and hcspmm_forward_fused the five fused launchers
+// (:596-863).  Differences by design: work goes to the caller's stream (the reference uses the
+// legacy default stream), every launch is checked (the reference checks none, :283-287), Z is the
+// caller's buffer, and nothing synchronises or allocates.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hcspmm.h"
+#include "spmm_kernels.h"
+
+namespace {
+thread_local int g_last_hip_error = 0;
+
+int fail_hip(hipError_t e) {
+  g_last_hip_error = (int)e;
+  return HCSPMM_EHIP;
+}
+
+inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
+// widest per-lane access the operands allow
+int pick_vec(int D, const void* X, const void* Z, const void* ws) {
+  if (D % 4 == 0 && aligned(X, 16) && aligned(Z, 16) && (!ws || aligned(ws, 16))) return 4;
+  if (D % 2 == 0 && aligned(X, 8) && aligned(Z, 8) && (!ws || aligned(ws, 8))) return 2;
+  return 1;
+}
+}  // namespace
+
+extern "C" const char* hcspmm_strerror(int code) {
+  switch (code) {
+    case HCSPMM_OK: return "ok";
+    case HCSPMM_EINVAL: return "invalid argument";
+    case HCSPMM_ENOMEM: return "host allocation failed";
+    case HCSPMM_EPLAN: return "plan does not match this graph (magic/version/N/E)";
+    case HCSPMM_EHIP: return "HIP runtime error (see hcspmm_last_hip_error)";
+    case HCSPMM_EWORKSPACE: return "workspace too small";
+    case HCSPMM_ERANGE: return "size exceeds the int32 index contract";
+    default: return "unknown hcspmm error";
+  }
+}
+
+extern "C" int hcspmm_abi_version(void) { return HCSPMM_ABI_VERSION; }
+extern "C" int hcspmm_last_hip_error(void) { return g_last_hip_error; }
+
+extern "C" int hcspmm_forward(const float* X, float* Z, const int32_t* rowptr, const int32_t* col,
+                              const int32_t* blockPartition, const int32_t* edgeToColumn, const int32_t* edgeToRow,
+                              const int32_t* hybrid_type, const int32_t* plan_d, const hcspmm_plan_header* ph,
+                              int64_t N, int64_t E, int D, void* workspace, size_t workspace_bytes, void* stream_v) {
+  if (N < 0 || E < 0 || D <= 0) return HCSPMM_EINVAL;
+  if (N == 0) return HCSPMM_OK;
+  if (!X || !Z || !rowptr || (E > 0 && !col)) return HCSPMM_EINVAL;
+  if (N > INT32_MAX - 16 || E > INT32_MAX) return HCSPMM_ERANGE;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+  hipError_t e;
+  if (plan_d && ph) {
+    const int rc = hcspmm_plan_check(ph, N, E);
+    if (rc != HCSPMM_OK) return rc;
+    const size_t need = hcspmm_workspace_bytes(ph, D);
+    if (need > 0 && (!workspace || workspace_bytes < need)) return HCSPMM_EWORKSPACE;
+    hcspmm::PlanArgs a;
+    a.X = X;
+    a.Z = Z;
+    a.partial = need ? reinterpret_cast<float*>(workspace) : nullptr;
+    a.col = col;
+    a.plan = plan_d;
+    a.off_tasks = ph->off_tasks;
+    a.n_tasks = ph->n_tasks;
+    a.off_dense_index = ph->off_dense_index;
+    a.off_dense_pack = ph->off_dense_pack;
+    a.n_dense = ph->n_dense;
+    a.off_fixups = ph->off_fixups;
+    a.n_split_rows = ph->n_split_rows;
+    a.N = (int)N;
+    a.D = D;
+    a.sparse_wgs = 0;
+    a.n_panels = 0;
+    e = hcspmm::launch_plan(a, pick_vec(D, X, Z, need ? workspace : nullptr), stream);
+  } else {
+    if (plan_d || ph) return HCSPMM_EINVAL;  // both or neither
+    if (!blockPartition || !hybrid_type || (E > 0 && (!edgeToColumn || !edgeToRow))) return HCSPMM_EINVAL;
+    hcspmm::WindowArgs a;
+    a.X = X;
+    a.Z = Z;
+    a.rowptr = rowptr;
+    a.col = col;
+    a.blockPartition = blockPartition;
+    a.edgeToColumn = edgeToColumn;
+    a.edgeToRow = edgeToRow;
+    a.hybrid_type = hybrid_type;
+    a.N = (int)N;
+    a.D = D;
+    e = hcspmm::launch_window(a, pick_vec(D, X, Z, nullptr), stream);
+  }
+  return e == hipSuccess ? HCSPMM_OK : fail_hip(e);
+}
+
+extern "C" int hcspmm_forward_fused(const float* X, float* out, float* out2, const float* weights, int64_t ldr,
+                                    int64_t ldc, int H, const int32_t* rowptr, const int32_t* col,
+                                    const int32_t* blockPartition, const int32_t* edgeToColumn,
+                                    const int32_t* edgeToRow, const int32_t* hybrid_type, const int32_t* plan_d,
+                                    const hcspmm_plan_header* ph, int64_t N, int64_t E, int D, void* workspace,
+                                    size_t workspace_bytes, void* stream_v) {
+  if (!out || !out2 || !weights || H <= 0) return HCSPMM_EINVAL;
+  const int rc = hcspmm_forward(X, out2, rowptr, col, blockPartition, edgeToColumn, edgeToRow, hybrid_type, plan_d, ph,
+                                N, E, D, workspace, workspace_bytes, stream_v);
+  if (rc != HCSPMM_OK) return rc;
+  const hipError_t e = hcspmm::launch_dense_update(out2, weights, (long long)ldr, (long long)ldc, out, (int)N, D, H,
+                                                   reinterpret_cast<hipStream_t>(stream_v));
+  return e == hipSuccess ? HCSPMM_OK : fail_hip(e);
+}

@@ -1,0 +1,235 @@
+// plan_host.cpp -- host-side launch plan for the gfx950 hybrid kernel (hcspmm_plan_*).
+//
+// New design (nothing comparable in the reference, which launches one block per window and
+// lets hub rows serialise, hybrid_all_kernel.cu:435-438): the classified windows are turned into
+//   tasks   : one per sparse-path row (rows longer than split_threshold are cut into segments of
+//             segment_len entries whose partial sums a fix-up pass adds in order); tasks are
+//             sorted by descending length so that (a) the 64/L tasks sharing a wave have nearly
+//             equal trip counts and (b) the hardware dispatcher sees the heaviest work first;
+//   dense   : per dense-path window, its ascending unique columns (K = 8*blockPartition, padded
+//             with -1) and, per 4-column k-step, the 64-bit lane mask of the 16x4 0/1 tile in
+//             v_mfma_f32_16x16x4_f32 A-operand order (lane = 16*(k%4) + row);
+//   fixups  : (row, first partial slot, segment count) for every split row.
+// Blob layout (int32 words): header[32] | tasks[n_tasks][4] | dense_index[n_dense][4] |
+// dense_pack[...] | fixups[n_split_rows][4].  All section offsets are multiples of 4 words.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "hcspmm.h"
+
+namespace {
+
+struct Resolved {
+  int32_t split_threshold, segment_len;
+};
+
+Resolved resolve(const hcspmm_plan_params* p) {
+  Resolved r{512, 256};
+  if (p) {
+    if (p->split_threshold > 0) r.split_threshold = p->split_threshold;
+    if (p->segment_len > 0) r.segment_len = p->segment_len;
+  }
+  if (r.segment_len > r.split_threshold) r.segment_len = r.split_threshold;
+  return r;
+}
+
+inline int64_t align4(int64_t x) { return (x + 3) & ~int64_t(3); }
+
+struct Layout {
+  int64_t n_tasks = 0, n_dense = 0, n_split_rows = 0, n_partials = 0;
+  int64_t dense_pack_words = 0;
+  int64_t nnz_sparse = 0, nnz_dense = 0;
+  int32_t max_dense_k = 0;
+  int64_t off_tasks = 0, off_dense_index = 0, off_dense_pack = 0, off_fixups = 0, total = 0;
+};
+
+int compute_layout(const int32_t* rowptr, int64_t N, const int32_t* bp, const int32_t* ht, const Resolved& rp,
+                   Layout* out) {
+  Layout L;
+  const int64_t W = (N + HCSPMM_BLK_H - 1) / HCSPMM_BLK_H;
+  for (int64_t w = 0; w < W; ++w) {
+    const int64_t r0 = w * HCSPMM_BLK_H, r1 = std::min<int64_t>(r0 + HCSPMM_BLK_H, N);
+    const int64_t nnz = (int64_t)rowptr[r1] - rowptr[r0];
+    if (ht[w] != 0 && nnz > 0) {
+      if (bp[w] <= 0) return HCSPMM_EINVAL;
+      L.n_dense++;
+      const int64_t K = (int64_t)bp[w] * HCSPMM_BLK_W;
+      L.dense_pack_words += K + (K / 4) * 2;  // U[K] + one 64-bit mask per 4 columns
+      L.nnz_dense += nnz;
+      L.max_dense_k = std::max<int32_t>(L.max_dense_k, (int32_t)K);
+    } else {
+      for (int64_t r = r0; r < r1; ++r) {
+        const int64_t d = (int64_t)rowptr[r + 1] - rowptr[r];
+        if (d > rp.split_threshold) {
+          const int64_t segs = (d + rp.segment_len - 1) / rp.segment_len;
+          L.n_tasks += segs;
+          L.n_partials += segs;
+          L.n_split_rows++;
+        } else {
+          L.n_tasks++;
+        }
+      }
+      L.nnz_sparse += nnz;
+    }
+  }
+  L.off_tasks = HCSPMM_PLAN_HEADER_WORDS;
+  L.off_dense_index = align4(L.off_tasks + 4 * L.n_tasks);
+  L.off_dense_pack = align4(L.off_dense_index + 4 * L.n_dense);
+  L.off_fixups = align4(L.off_dense_pack + L.dense_pack_words);
+  L.total = align4(L.off_fixups + 4 * L.n_split_rows);
+  if (L.total > INT32_MAX) return HCSPMM_ERANGE;
+  *out = L;
+  return HCSPMM_OK;
+}
+
+}  // namespace
+
+extern "C" int hcspmm_plan_words(const int32_t* rowptr, int64_t N, int64_t E, const int32_t* bp, const int32_t* ht,
+                                 const hcspmm_plan_params* params, int64_t* words_out) {
+  if (!rowptr || !words_out || N < 0 || E < 0) return HCSPMM_EINVAL;
+  if (N > 0 && (!bp || !ht)) return HCSPMM_EINVAL;
+  Layout L;
+  const int rc = compute_layout(rowptr, N, bp, ht, resolve(params), &L);
+  if (rc != HCSPMM_OK) return rc;
+  *words_out = L.total;
+  return HCSPMM_OK;
+}
+
+extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const int32_t* bp,
+                                 const int32_t* e2c, const int32_t* ht, const hcspmm_plan_params* params,
+                                 int32_t* plan, int64_t words) {
+  if (!rowptr || !plan || N < 0 || E < 0) return HCSPMM_EINVAL;
+  if (N > 0 && (!bp || !ht)) return HCSPMM_EINVAL;
+  if (E > 0 && (!col || !e2c)) return HCSPMM_EINVAL;
+  const Resolved rp = resolve(params);
+  Layout L;
+  int rc = compute_layout(rowptr, N, bp, ht, rp, &L);
+  if (rc != HCSPMM_OK) return rc;
+  if (words < L.total) return HCSPMM_EINVAL;
+  std::memset(plan, 0, sizeof(int32_t) * (size_t)L.total);
+  const int64_t W = (N + HCSPMM_BLK_H - 1) / HCSPMM_BLK_H;
+
+  // ---- sparse tasks: collect, then counting-sort by descending length (stable in row order)
+  struct Task { int32_t row, e0, len, slot; };
+  std::vector<Task> tasks;
+  tasks.reserve((size_t)L.n_tasks);
+  int32_t* fix = plan + L.off_fixups;
+  int64_t n_fix = 0, slot = 0;
+  struct DenseRef { int32_t w, K; };
+  std::vector<DenseRef> dense;
+  dense.reserve((size_t)L.n_dense);
+  for (int64_t w = 0; w < W; ++w) {
+    const int64_t r0 = w * HCSPMM_BLK_H, r1 = std::min<int64_t>(r0 + HCSPMM_BLK_H, N);
+    const int64_t nnz = (int64_t)rowptr[r1] - rowptr[r0];
+    if (ht[w] != 0 && nnz > 0) {
+      dense.push_back({(int32_t)w, bp[w] * HCSPMM_BLK_W});
+      continue;
+    }
+    for (int64_t r = r0; r < r1; ++r) {
+      const int32_t e0 = rowptr[r];
+      const int64_t d = (int64_t)rowptr[r + 1] - e0;
+      if (d > rp.split_threshold) {
+        const int64_t segs = (d + rp.segment_len - 1) / rp.segment_len;
+        fix[4 * n_fix + 0] = (int32_t)r;
+        fix[4 * n_fix + 1] = (int32_t)slot;
+        fix[4 * n_fix + 2] = (int32_t)segs;
+        ++n_fix;
+        for (int64_t s = 0; s < segs; ++s) {
+          const int64_t b = s * rp.segment_len;
+          tasks.push_back({(int32_t)r, (int32_t)(e0 + b), (int32_t)std::min<int64_t>(rp.segment_len, d - b),
+                           (int32_t)slot++});
+        }
+      } else {
+        tasks.push_back({(int32_t)r, e0, (int32_t)d, -1});
+      }
+    }
+  }
+  {
+    const int32_t maxlen = rp.split_threshold;
+    std::vector<int64_t> start((size_t)maxlen + 2, 0);
+    for (const Task& t : tasks) start[(size_t)(maxlen - t.len) + 1]++;  // bucket 0 = longest
+    for (size_t i = 1; i < start.size(); ++i) start[i] += start[i - 1];
+    int32_t* out = plan + L.off_tasks;
+    for (const Task& t : tasks) {
+      const int64_t p = start[(size_t)(maxlen - t.len)]++;
+      out[4 * p + 0] = t.row;
+      out[4 * p + 1] = t.e0;
+      out[4 * p + 2] = t.len;
+      out[4 * p + 3] = t.slot;
+    }
+  }
+
+  // ---- dense windows: widest first; pack U and the MFMA lane masks
+  std::stable_sort(dense.begin(), dense.end(), [](const DenseRef& a, const DenseRef& b) { return a.K > b.K; });
+  int32_t* dindex = plan + L.off_dense_index;
+  int32_t* dpack = plan + L.off_dense_pack;
+  int64_t pack_off = 0, uniq_total = 0;
+  for (size_t i = 0; i < dense.size(); ++i) {
+    const int64_t w = dense[i].w;
+    const int32_t K = dense[i].K, K4 = K / 4;
+    const int64_t r0 = w * HCSPMM_BLK_H, r1 = std::min<int64_t>(r0 + HCSPMM_BLK_H, N);
+    int32_t* U = dpack + pack_off;
+    uint32_t* masks = reinterpret_cast<uint32_t*>(U + K);  // little-endian halves of the 64-bit masks
+    for (int32_t k = 0; k < K; ++k) U[k] = -1;
+    for (int64_t r = r0; r < r1; ++r) {
+      for (int64_t e = rowptr[r]; e < rowptr[r + 1]; ++e) {
+        const int32_t c = e2c[e];
+        if (c < 0 || c >= K) return HCSPMM_EINVAL;
+        U[c] = col[e];
+        const int lane = 16 * (c & 3) + (int)(r - r0);
+        masks[(c >> 2) * 2 + (lane >> 5)] |= 1u << (lane & 31);
+      }
+    }
+    for (int32_t k = 0; k < K; ++k) uniq_total += U[k] >= 0;
+    dindex[4 * i + 0] = (int32_t)w;
+    dindex[4 * i + 1] = (int32_t)pack_off;
+    dindex[4 * i + 2] = K4;
+    dindex[4 * i + 3] = 0;
+    pack_off += K + K4 * 2;
+  }
+
+  hcspmm_plan_header h;
+  std::memset(&h, 0, sizeof(h));
+  h.magic = HCSPMM_PLAN_MAGIC;
+  h.version = HCSPMM_PLAN_VERSION;
+  h.total_words = (int32_t)L.total;
+  h.num_nodes = (int32_t)N;
+  h.num_edges = (int32_t)E;
+  h.num_windows = (int32_t)W;
+  h.split_threshold = rp.split_threshold;
+  h.segment_len = rp.segment_len;
+  h.n_tasks = (int32_t)L.n_tasks;
+  h.n_dense = (int32_t)L.n_dense;
+  h.n_split_rows = (int32_t)L.n_split_rows;
+  h.n_partials = (int32_t)L.n_partials;
+  h.off_tasks = (int32_t)L.off_tasks;
+  h.off_dense_index = (int32_t)L.off_dense_index;
+  h.off_dense_pack = (int32_t)L.off_dense_pack;
+  h.off_fixups = (int32_t)L.off_fixups;
+  h.nnz_sparse = (int32_t)L.nnz_sparse;
+  h.nnz_dense = (int32_t)L.nnz_dense;
+  h.uniq_dense = (int32_t)uniq_total;
+  h.max_dense_k = L.max_dense_k;
+  static_assert(sizeof(hcspmm_plan_header) == HCSPMM_PLAN_HEADER_WORDS * 4, "header size");
+  std::memcpy(plan, &h, sizeof(h));
+  return HCSPMM_OK;
+}
+
+extern "C" int hcspmm_plan_check(const hcspmm_plan_header* h, int64_t N, int64_t E) {
+  if (!h) return HCSPMM_EINVAL;
+  if (h->magic != HCSPMM_PLAN_MAGIC || h->version != HCSPMM_PLAN_VERSION) return HCSPMM_EPLAN;
+  if (h->num_nodes != N || h->num_edges != E) return HCSPMM_EPLAN;
+  if (h->n_tasks < 0 || h->n_dense < 0 || h->n_split_rows < 0 || h->n_partials < 0) return HCSPMM_EPLAN;
+  if (h->off_tasks < HCSPMM_PLAN_HEADER_WORDS || h->off_dense_index < h->off_tasks ||
+      h->off_dense_pack < h->off_dense_index || h->off_fixups < h->off_dense_pack ||
+      h->total_words < h->off_fixups)
+    return HCSPMM_EPLAN;
+  return HCSPMM_OK;
+}
+
+extern "C" size_t hcspmm_workspace_bytes(const hcspmm_plan_header* h, int D) {
+  if (!h || D <= 0) return 0;
+  return (size_t)h->n_partials * (size_t)D * sizeof(float);
+}

@@ -1,0 +1,111 @@
+// preprocess_host.cpp -- host-side window condensing + classifier (hcspmm_preprocess_host).
+//
+// Produces the four integer products of the reference's `preprocess`
+// (hybrid_kernel/hybrid_all_kernel.cu:339-408): edgeToRow (:314-326), and per 16-row window the
+// number of 8-column blocks of its condensed form, the sparse/dense class and each entry's
+// condensed column (:242-269, on the per-window sorted copy that :386-399 makes with
+// thrust::sort).  The reference does this with one GPU thread per window; north_star puts it on
+// the host, so here windows are spread over host threads in nnz-balanced contiguous ranges, and
+// per window the sorted unique column list is built once and every row is ranked against it with
+// a linear merge (rows are ascending, so no per-entry binary search is needed).
+#include <algorithm>
+#include <cstdint>
+#include <thread>
+#include <vector>
+
+#include "hcspmm.h"
+
+namespace {
+
+// The classifier expression of hybrid_all_kernel.cu:261-262 with the reference's C types:
+// (float)size * <double> - ((float)nnz / (int)(num*16*8)) * <double> - <double>; the quotient is
+// a float division.  Built with -ffp-contract=off so no term is fused.
+inline int classify(int32_t size, uint32_t nnz, int32_t num, int rule) {
+  const double t1 = (double)((float)size) * 0.19854024;
+  const float dens = (float)nnz / (float)(num * HCSPMM_BLK_H * HCSPMM_BLK_W);
+  const double t2 = (double)dens * 6.578043;
+  const double logit = (t1 - t2) - 3.14922857;
+  switch (rule) {
+    case HCSPMM_RULE_INTENDED: return logit > 0 ? 0 : 1;
+    case HCSPMM_RULE_INTENDED_GUARD: return (size > 32 || logit > 0) ? 0 : 1;
+    default: return logit != 0.0 ? 0 : 1;
+  }
+}
+
+void process_windows(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t w_begin, int64_t w_end, int rule,
+                     int32_t* blockPartition, int32_t* edgeToColumn, int32_t* edgeToRow, int32_t* hybrid_type) {
+  std::vector<int32_t> uniq;
+  for (int64_t w = w_begin; w < w_end; ++w) {
+    const int64_t r0 = w * HCSPMM_BLK_H, r1 = std::min<int64_t>(r0 + HCSPMM_BLK_H, N);
+    const int64_t lo = rowptr[r0], hi = rowptr[r1];
+    for (int64_t r = r0; r < r1; ++r)
+      for (int64_t e = rowptr[r]; e < rowptr[r + 1]; ++e) edgeToRow[e] = (int32_t)r;
+    if (hi == lo) {  // reference returns early and leaves garbage (K.cu:252-253); defined as 0/0
+      blockPartition[w] = 0;
+      hybrid_type[w] = 0;
+      continue;
+    }
+    uniq.assign(col + lo, col + hi);
+    std::sort(uniq.begin(), uniq.end());
+    uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+    const int32_t size = (int32_t)uniq.size() - 1;                      // K.cu:256-257
+    const int32_t num = (size + HCSPMM_BLK_W) / HCSPMM_BLK_W;           // K.cu:258
+    blockPartition[w] = num;
+    hybrid_type[w] = classify(size, (uint32_t)(hi - lo), num, rule);
+    for (int64_t r = r0; r < r1; ++r) {
+      const int64_t a = rowptr[r], b = rowptr[r + 1];
+      bool ascending = true;
+      for (int64_t e = a + 1; e < b; ++e) ascending &= col[e - 1] <= col[e];
+      if (ascending) {  // merge walk: both sequences ascending
+        size_t p = 0;
+        for (int64_t e = a; e < b; ++e) {
+          while (uniq[p] < col[e]) ++p;
+          edgeToColumn[e] = (int32_t)p;
+        }
+      } else {  // unsorted row (not produced by dataset.py, but the reference's search copes)
+        for (int64_t e = a; e < b; ++e)
+          edgeToColumn[e] = (int32_t)(std::lower_bound(uniq.begin(), uniq.end(), col[e]) - uniq.begin());
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int hcspmm_preprocess_host(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, int rule,
+                                      int num_threads, int32_t* blockPartition, int32_t* edgeToColumn,
+                                      int32_t* edgeToRow, int32_t* hybrid_type) {
+  if (N < 0 || E < 0 || !rowptr) return HCSPMM_EINVAL;
+  if (E > 0 && (!col || !edgeToColumn || !edgeToRow)) return HCSPMM_EINVAL;
+  if (rule < HCSPMM_RULE_INTENDED || rule > HCSPMM_RULE_AS_SHIPPED) return HCSPMM_EINVAL;
+  if (N > INT32_MAX - 16 || E > INT32_MAX) return HCSPMM_ERANGE;
+  const int64_t W = (N + HCSPMM_BLK_H - 1) / HCSPMM_BLK_H;
+  if (W > 0 && (!blockPartition || !hybrid_type)) return HCSPMM_EINVAL;
+  if (rowptr[0] != 0 || rowptr[N] != E) return HCSPMM_EINVAL;
+  for (int64_t r = 0; r < N; ++r)
+    if (rowptr[r + 1] < rowptr[r]) return HCSPMM_EINVAL;
+
+  int T = num_threads > 0 ? num_threads : (int)std::thread::hardware_concurrency();
+  if (T < 1) T = 1;
+  if (W < 4 * T || E < (1 << 16)) T = 1;
+  if (T == 1) {
+    process_windows(rowptr, col, N, 0, W, rule, blockPartition, edgeToColumn, edgeToRow, hybrid_type);
+    return HCSPMM_OK;
+  }
+  // contiguous window ranges with ~equal (entries + windows) each
+  std::vector<int64_t> cut(T + 1, W);
+  cut[0] = 0;
+  const double total = (double)E + (double)W;
+  int64_t w = 0;
+  for (int t = 1; t < T; ++t) {
+    const double target = total * t / T;
+    while (w < W && (double)rowptr[std::min<int64_t>(w * HCSPMM_BLK_H, N)] + (double)w < target) ++w;
+    cut[t] = w;
+  }
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; ++t)
+    th.emplace_back(process_windows, rowptr, col, N, cut[t], cut[t + 1], rule, blockPartition, edgeToColumn, edgeToRow,
+                    hybrid_type);
+  for (auto& x : th) x.join();
+  return HCSPMM_OK;
+}

@@ -1,0 +1,45 @@
+// spmm_kernels.h -- internal launch interface between capi.hip and spmm_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hcspmm {
+
+// Arguments of the planned hybrid launch (device pointers; `plan` is the uploaded blob of
+// hcspmm_plan_build, the off_* / n_* fields are copied from the host copy of its header).
+struct PlanArgs {
+  const float* X;
+  float* Z;
+  float* partial;  // workspace: n_partials x D partial sums of split rows
+  const int* col;
+  const int* plan;
+  int off_tasks, n_tasks;
+  int off_dense_index, off_dense_pack, n_dense;
+  int off_fixups, n_split_rows;
+  int N, D;
+  int sparse_wgs, n_panels;  // filled by the launcher
+};
+
+// Arguments of the plan-free launch: the reference's seven graph tensors as they are.
+struct WindowArgs {
+  const float* X;
+  float* Z;
+  const int* rowptr;
+  const int* col;
+  const int* blockPartition;
+  const int* edgeToColumn;
+  const int* edgeToRow;
+  const int* hybrid_type;
+  int N, D;
+};
+
+// vec = floats per lane access (4, 2 or 1): the caller guarantees D % vec == 0 and that X, Z and
+// the workspace are aligned to 4*vec bytes.
+hipError_t launch_plan(const PlanArgs& a, int vec, hipStream_t stream);
+hipError_t launch_window(const WindowArgs& a, int vec, hipStream_t stream);
+
+// out[N x H] = in[N x D] * W (D x H, element strides ldr / ldc), fp32 MFMA.
+hipError_t launch_dense_update(const float* in, const float* W, long long ldr, long long ldc, float* out, int N,
+                               int D, int H, hipStream_t stream);
+
+}  // namespace hcspmm

@@ -1,0 +1,356 @@
+// spmm_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the hybrid SpMM  Z = A * X.
+//
+// Replaces the reference kernels spmm_forward_cuda_kernel_arbi_warps_hybrid_{adaptive,32,64,
+// adaptive_more} (hybrid_kernel/hybrid_all_kernel.cu:919-1637).  Nothing here is derived from
+// their structure: the reference runs one 96-thread block per 16-row window with warp-per-row
+// gathers and WMMA tf32 tiles staged through shared memory; this file is wave64 code built
+// around two facts of the machine (see /DESIGN.md):
+//
+//  * sparse-row path: the path is bound by how many gathered X-row bytes a CU keeps in flight,
+//    so rows become length-sorted *tasks* (host plan), L lanes of a wave own one task and walk
+//    its neighbours strictly in CSR order (bit-identical to a sequential fp32 sum), 64/L tasks
+//    share a wave, column indices are fetched coalesced once per L neighbours and broadcast
+//    through the LDS crossbar (ds_bpermute), and every lane issues 16-byte loads, U deep.
+//  * dense-tile path: v_mfma_f32_16x16x4_f32 takes its B operand one fp32 per lane, so the
+//    gathered X rows go from HBM straight into MFMA operand registers with 16-byte loads (the
+//    four floats of a lane feed four MFMAs whose results re-assemble into a 16-byte store);
+//    the 0/1 tile of A arrives as a 64-bit lane mask per k-step, packed by the host in MFMA
+//    lane order.  No LDS round trip, no barrier.  fp32 MFMA is an exact k-ordered fma chain,
+//    so the result equals the sequential sum over the window's ascending unique columns.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "spmm_kernels.h"
+
+namespace hcspmm {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int VEC> struct VecT;
+template <> struct VecT<4> { typedef f32x4 type; };
+template <> struct VecT<2> { typedef f32x2 type; };
+template <> struct VecT<1> { typedef float type; };
+
+template <int VEC> __device__ __forceinline__ typename VecT<VEC>::type vzero();
+template <> __device__ __forceinline__ f32x4 vzero<4>() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+template <> __device__ __forceinline__ f32x2 vzero<2>() { return f32x2{0.f, 0.f}; }
+template <> __device__ __forceinline__ float vzero<1>() { return 0.f; }
+
+__device__ __forceinline__ float vget(const f32x4& v, int i) { return v[i]; }
+__device__ __forceinline__ float vget(const f32x2& v, int i) { return v[i]; }
+__device__ __forceinline__ float vget(const float& v, int) { return v; }
+__device__ __forceinline__ void vset(f32x4& v, int i, float x) { v[i] = x; }
+__device__ __forceinline__ void vset(f32x2& v, int i, float x) { v[i] = x; }
+__device__ __forceinline__ void vset(float& v, int, float x) { v = x; }
+
+constexpr int kWaves = 4;            // waves per workgroup (256 threads)
+constexpr int kThreads = kWaves * 64;
+
+// ------------------------------------------------------------------------------------------
+// Sparse-row task body: the L lanes [lane & ~(L-1), +L) own one task (row or row segment)
+// = CSR entries [e0, e0 + n); lane slot s covers columns pbase + s*VEC .. +VEC.  All control
+// flow is wave-uniform (loop bounds come from the wave-wide maximum n); shorter tasks are
+// predicated off by idx = -1, and adding the resulting 0.0f is exact.
+// ------------------------------------------------------------------------------------------
+template <int L, int VEC>
+__device__ __forceinline__ void sparse_task(const float* __restrict__ X, float* __restrict__ dst,
+                                            const int* __restrict__ col, int e0, int n, int D, int lane) {
+  typedef typename VecT<VEC>::type vec_t;
+  constexpr int U = (L < 8) ? L : 8;  // loads in flight per lane
+  const int s = lane & (L - 1);
+  const int gbase = lane & ~(L - 1);
+  int nmax = n;
+#pragma unroll
+  for (int off = L; off < 64; off <<= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
+  nmax = __builtin_amdgcn_readfirstlane(nmax);
+
+  for (int pbase = 0; pbase < D; pbase += L * VEC) {
+    const int c = pbase + s * VEC;
+    const bool cok = c < D;
+    vec_t acc = vzero<VEC>();
+    for (int base = 0; base < nmax; base += L) {
+      const int myidx = (base + s < n) ? col[e0 + base + s] : -1;
+      const int cnt = min(L, nmax - base);
+      for (int j = 0; j < cnt; j += U) {
+        vec_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int idx = __shfl(myidx, gbase + j + u, 64);
+          v[u] = vzero<VEC>();
+          if (cok && idx >= 0) v[u] = *reinterpret_cast<const vec_t*>(X + (size_t)idx * (size_t)D + c);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += v[u];
+      }
+    }
+    if (cok && dst != nullptr) *reinterpret_cast<vec_t*>(dst + c) = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Dense-tile unit: one wave = (dense window, panel of 16*VEC feature columns).
+// MFMA operand maps (v_mfma_f32_16x16x4_f32): lane l supplies A[i = l & 15][k = l >> 4] and
+// B[k = l >> 4][j = l & 15]; accumulator register r of lane l is D[4*(l >> 4) + r][l & 15].
+// Instruction q of a k-step multiplies by feature column  panel + j*VEC + q, so after the VEC
+// instructions lane l holds Z[row 4*(l>>4)+r][panel + j*VEC .. +VEC) -- a contiguous vector.
+// ------------------------------------------------------------------------------------------
+template <int VEC>
+__device__ __forceinline__ void dense_unit(const float* __restrict__ X, float* __restrict__ Z,
+                                           const int* __restrict__ U, const unsigned long long* __restrict__ masks,
+                                           int K4, int window, int panel, int N, int D, int lane) {
+  typedef typename VecT<VEC>::type vec_t;
+  const int kq = lane >> 4, j = lane & 15;
+  const int c = panel * 16 * VEC + j * VEC;
+  const bool cok = c < D;
+  f32x4 acc[VEC];
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int kb = 0; kb < K4; kb += 16) {
+    const int myU = (kb * 4 + lane < K4 * 4) ? U[kb * 4 + lane] : -1;
+    const int steps = min(16, K4 - kb);
+    for (int t0 = 0; t0 < steps; t0 += 4) {
+      vec_t x[4];
+      float a[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = t0 + u;  // may run past `steps`: U pad (-1) and zero masks make it a no-op
+        const int idx = (t < steps) ? __shfl(myU, (4 * t + kq) & 63, 64) : -1;
+        const unsigned long long m = (t < steps) ? masks[kb + t] : 0ull;
+        a[u] = ((m >> lane) & 1ull) ? 1.0f : 0.0f;
+        x[u] = vzero<VEC>();
+        if (cok && idx >= 0) x[u] = *reinterpret_cast<const vec_t*>(X + (size_t)idx * (size_t)D + c);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q)
+          acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], vget(x[u], q), acc[q], 0, 0, 0);
+      }
+    }
+  }
+  if (cok) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = window * 16 + 4 * kq + r;
+      if (row < N) {
+        vec_t o;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) vset(o, q, acc[q][r]);
+        *reinterpret_cast<vec_t*>(Z + (size_t)row * (size_t)D + c) = o;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Planned hybrid kernel: ONE launch covers both sub-paths (as the reference's single launch
+// does, K.cu:960/1039) -- workgroups [0, sparse_wgs) run sparse tasks, the rest dense units.
+// ------------------------------------------------------------------------------------------
+template <int L, int VEC>
+__global__ __launch_bounds__(kThreads) void hybrid_plan_kernel(PlanArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if ((int)blockIdx.x < a.sparse_wgs) {
+    constexpr int R = 64 / L;
+    const int g = lane / L;
+    const int tid = ((int)blockIdx.x * kWaves + wave) * R + g;
+    int e0 = 0, n = 0;
+    float* dst = nullptr;
+    if (tid < a.n_tasks) {
+      const int4 t = reinterpret_cast<const int4*>(a.plan + a.off_tasks)[tid];
+      e0 = t.y;
+      n = t.z;
+      dst = (t.w < 0) ? a.Z + (size_t)t.x * (size_t)a.D : a.partial + (size_t)t.w * (size_t)a.D;
+    }
+    sparse_task<L, VEC>(a.X, dst, a.col, e0, n, a.D, lane);
+  } else {
+    const int unit = ((int)blockIdx.x - a.sparse_wgs) * kWaves + wave;
+    if (unit >= a.n_dense * a.n_panels) return;
+    const int di = unit / a.n_panels, panel = unit - di * a.n_panels;
+    const int4 d = reinterpret_cast<const int4*>(a.plan + a.off_dense_index)[di];
+    const int* U = a.plan + a.off_dense_pack + d.y;
+    const unsigned long long* masks = reinterpret_cast<const unsigned long long*>(U + 4 * d.z);
+    dense_unit<VEC>(a.X, a.Z, U, masks, d.z, d.x, panel, a.N, a.D, lane);
+  }
+}
+
+// Fix-up: rows that were split into segments -- Z[row] = partial[s0] + partial[s0+1] + ... in
+// segment order (deterministic).  One wave per split row.
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void fixup_kernel(PlanArgs a) {
+  typedef typename VecT<VEC>::type vec_t;
+  const int lane = threadIdx.x & 63;
+  const int fi = (int)blockIdx.x * kWaves + (threadIdx.x >> 6);
+  if (fi >= a.n_split_rows) return;
+  const int4 f = reinterpret_cast<const int4*>(a.plan + a.off_fixups)[fi];
+  const int row = f.x, s0 = f.y, ns = f.z;
+  for (int c = lane * VEC; c < a.D; c += 64 * VEC) {
+    vec_t acc = *reinterpret_cast<const vec_t*>(a.partial + (size_t)s0 * (size_t)a.D + c);
+    for (int s = 1; s < ns; ++s) acc += *reinterpret_cast<const vec_t*>(a.partial + (size_t)(s0 + s) * (size_t)a.D + c);
+    *reinterpret_cast<vec_t*>(a.Z + (size_t)row * (size_t)a.D + c) = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Plan-free kernel (callers that pass the reference's [0] placeholders): one workgroup per
+// 16-row window, branch on hybrid_type[window] exactly like the reference launch.  Sparse
+// windows deal their rows to the workgroup's lane groups; dense windows rebuild the window's
+// unique-column list and tile masks in LDS from edgeToColumn / edgeToRow / column_index (the
+// reference builds sparse_A / sparse_AToX_index the same way, K.cu:1067-1074) in chunks of
+// kChunkK condensed columns, so any blockPartition is handled.
+// ------------------------------------------------------------------------------------------
+constexpr int kChunkK = 512;  // condensed columns per LDS pass (128 k-steps)
+
+template <int L, int VEC>
+__global__ __launch_bounds__(kThreads) void hybrid_window_kernel(WindowArgs a) {
+  __shared__ int s_U[kChunkK];
+  __shared__ unsigned int s_mask[kChunkK / 4 * 2];  // 64-bit lane masks as two 32-bit halves
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int w = blockIdx.x;
+  const int r0 = w * 16, r1 = min(r0 + 16, a.N);
+  if (a.hybrid_type[w] == 0) {
+    constexpr int R = 64 / L;
+    constexpr int G = R * kWaves;  // lane groups per workgroup
+    const int gi = wave * R + lane / L;
+    for (int rb = r0; rb < r1; rb += G) {  // uniform
+      const int r = rb + gi;
+      int e0 = 0, n = 0;
+      float* dst = nullptr;
+      if (r < r1) {
+        e0 = a.rowptr[r];
+        n = a.rowptr[r + 1] - e0;
+        dst = a.Z + (size_t)r * (size_t)a.D;
+      }
+      sparse_task<L, VEC>(a.X, dst, a.col, e0, n, a.D, lane);
+    }
+    return;
+  }
+  typedef typename VecT<VEC>::type vec_t;
+  const int lo = a.rowptr[r0], hi = a.rowptr[r1];
+  const int K = a.blockPartition[w] * 8;
+  const int n_panels = (a.D + 16 * VEC - 1) / (16 * VEC);
+  const int kq = lane >> 4, j = lane & 15;
+  for (int pb = 0; pb < n_panels; pb += kWaves) {  // uniform over the workgroup
+    const int panel = pb + wave;
+    const int c = panel * 16 * VEC + j * VEC;
+    const bool cok = panel < n_panels && c < a.D;
+    f32x4 acc[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += kChunkK) {  // uniform
+      const int kc = min(kChunkK, K - k0);
+      __syncthreads();
+      for (int i = threadIdx.x; i < kChunkK; i += kThreads) s_U[i] = -1;
+      for (int i = threadIdx.x; i < kChunkK / 2; i += kThreads) s_mask[i] = 0u;
+      __syncthreads();
+      for (int e = lo + (int)threadIdx.x; e < hi; e += kThreads) {
+        const int cc = a.edgeToColumn[e] - k0;
+        if (cc >= 0 && cc < kc) {
+          const int rl = a.edgeToRow[e] - r0;
+          const int bit = 16 * (cc & 3) + rl;  // MFMA A-operand lane of (row rl, k = cc & 3)
+          atomicOr(&s_mask[(cc >> 2) * 2 + (bit >> 5)], 1u << (bit & 31));
+          s_U[cc] = a.col[e];
+        }
+      }
+      __syncthreads();
+      const int steps = (kc + 3) / 4;
+      for (int t0 = 0; t0 < steps; t0 += 4) {
+        vec_t x[4];
+        float av[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int t = t0 + u;
+          const bool tv = t < steps;
+          const int idx = tv ? s_U[min(4 * t + kq, kChunkK - 1)] : -1;
+          const unsigned int mw = tv ? s_mask[t * 2 + (lane >> 5)] : 0u;
+          av[u] = ((mw >> (lane & 31)) & 1u) ? 1.0f : 0.0f;
+          x[u] = vzero<VEC>();
+          if (cok && idx >= 0) x[u] = *reinterpret_cast<const vec_t*>(a.X + (size_t)idx * (size_t)a.D + c);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+          for (int q = 0; q < VEC; ++q)
+            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], vget(x[u], q), acc[q], 0, 0, 0);
+        }
+      }
+    }
+    if (cok) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = r0 + 4 * kq + r;
+        if (row < a.N) {
+          vec_t o;
+#pragma unroll
+          for (int q = 0; q < VEC; ++q) vset(o, q, acc[q][r]);
+          *reinterpret_cast<vec_t*>(a.Z + (size_t)row * (size_t)a.D + c) = o;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Host-side dispatch on (L, VEC).
+// ------------------------------------------------------------------------------------------
+template <int L, int VEC>
+static hipError_t launch_plan_LV(const PlanArgs& a, hipStream_t stream) {
+  constexpr int R = 64 / L;
+  PlanArgs b = a;
+  b.sparse_wgs = (a.n_tasks + kWaves * R - 1) / (kWaves * R);
+  b.n_panels = (a.D + 16 * VEC - 1) / (16 * VEC);
+  const long long dense_units = (long long)a.n_dense * b.n_panels;
+  const long long dense_wgs = (dense_units + kWaves - 1) / kWaves;
+  const long long grid = (long long)b.sparse_wgs + dense_wgs;
+  if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  if (grid > 0) hipLaunchKernelGGL((hybrid_plan_kernel<L, VEC>), dim3((unsigned)grid), dim3(kThreads), 0, stream, b);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if (a.n_split_rows > 0) {
+    const int fg = (a.n_split_rows + kWaves - 1) / kWaves;
+    hipLaunchKernelGGL((fixup_kernel<VEC>), dim3(fg), dim3(kThreads), 0, stream, b);
+    e = hipGetLastError();
+  }
+  return e;
+}
+
+template <int L, int VEC>
+static hipError_t launch_window_LV(const WindowArgs& a, hipStream_t stream) {
+  const int W = (a.N + 15) / 16;
+  if (W > 0) hipLaunchKernelGGL((hybrid_window_kernel<L, VEC>), dim3(W), dim3(kThreads), 0, stream, a);
+  return hipGetLastError();
+}
+
+// lanes per task: smallest power of two >= D / VEC, clamped to [4, 64]
+static int pick_L(int D, int VEC) {
+  const int slots = (D + VEC - 1) / VEC;
+  int L = 4;
+  while (L < slots && L < 64) L <<= 1;
+  return L;
+}
+
+#define HCSPMM_DISPATCH_L(FN, VEC, ARGS, STREAM)            \
+  switch (pick_L((ARGS).D, VEC)) {                          \
+    case 4:  return FN<4, VEC>(ARGS, STREAM);               \
+    case 8:  return FN<8, VEC>(ARGS, STREAM);               \
+    case 16: return FN<16, VEC>(ARGS, STREAM);              \
+    case 32: return FN<32, VEC>(ARGS, STREAM);              \
+    default: return FN<64, VEC>(ARGS, STREAM);              \
+  }
+
+hipError_t launch_plan(const PlanArgs& a, int vec, hipStream_t stream) {
+  if (vec == 4) { HCSPMM_DISPATCH_L(launch_plan_LV, 4, a, stream) }
+  if (vec == 2) { HCSPMM_DISPATCH_L(launch_plan_LV, 2, a, stream) }
+  HCSPMM_DISPATCH_L(launch_plan_LV, 1, a, stream)
+}
+
+hipError_t launch_window(const WindowArgs& a, int vec, hipStream_t stream) {
+  if (vec == 4) { HCSPMM_DISPATCH_L(launch_window_LV, 4, a, stream) }
+  if (vec == 2) { HCSPMM_DISPATCH_L(launch_window_LV, 2, a, stream) }
+  HCSPMM_DISPATCH_L(launch_window_LV, 1, a, stream)
+}
+
+}  // namespace hcspmm

@@ -1,0 +1,266 @@
+"""hcspmm -- Python host glue over the C ABI of libhcspmm.so (include/hcspmm.h).
+
+Mirrors the operator surface of the reference's `HCSPMM` extension module
+(/root/reference/hybrid_kernel/hybrid_all.cpp:500-525): `preprocess`, `forward`,
+`forward_more`, `forward_fixed32`, `forward_fixed64`, the fused variants and the `backward*`
+aliases, with the same positional arguments and return lists, so code written against the
+reference calls it unchanged.  Tensors are plumbing only (device memory + streams); all work
+happens behind the C ABI.  There is NO CPU fallback: if libhcspmm.so is missing, or a feature
+tensor is not on the GPU, the call raises.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+from .capi import (Header, PlanParams, RULE_AS_SHIPPED, RULE_INTENDED, RULE_INTENDED_GUARD, check, lib)
+
+__all__ = [
+    "preprocess", "forward", "forward_more", "forward_fixed32", "forward_fixed64", "forward_fixed32_fused",
+    "forward_fixed64_fused", "forward_final_fused", "forward_final_fused_64", "forward_GIN_final_fused", "backward",
+    "backward_fixed32", "backward_fixed32_fused", "backward_final_fused", "backward_fixed64",
+    "backward_fixed64_fused", "backward_final_fused_64", "backward_GIN_final_fused", "loi_reorder",
+    "apply_permutation", "plan_header", "forward_rect", "set_default_rule", "RULE_INTENDED", "RULE_INTENDED_GUARD",
+    "RULE_AS_SHIPPED",
+]
+
+_DEFAULT_RULE = int(os.environ.get("HCSPMM_RULE", RULE_INTENDED))
+_PLAN_PARAMS = PlanParams(int(os.environ.get("HCSPMM_SPLIT_THRESHOLD", 0)), int(os.environ.get("HCSPMM_SEGMENT_LEN", 0)))
+
+
+def set_default_rule(rule):
+    """Classifier rule used by preprocess(): RULE_INTENDED (default), _GUARD or _AS_SHIPPED."""
+    global _DEFAULT_RULE
+    _DEFAULT_RULE = int(rule)
+
+
+# ---------------------------------------------------------------------------------------------
+# plan registry: data_ptr of a plan tensor -> (tensor kept alive, host copy of its header).
+# Holding the tensor keeps its address from being reused, so the key stays unambiguous.
+# ---------------------------------------------------------------------------------------------
+_REG = {}
+_REG_LOCK = threading.Lock()
+_REG_MAX = 256
+
+
+def _register(plan_t, header):
+    with _REG_LOCK:
+        if len(_REG) >= _REG_MAX:
+            _REG.pop(next(iter(_REG)))
+        _REG[plan_t.data_ptr()] = (plan_t, header)
+
+
+def plan_header(row_nzr, num_nodes=None, num_edges=None):
+    """Host copy of the plan header carried by `row_nzr`, or None for the reference's [0]
+    placeholder.  A plan tensor first seen here (e.g. a clone) costs one small device read."""
+    if row_nzr is None or row_nzr.numel() < Header.WORDS or row_nzr.dtype != torch.int32:
+        return None
+    hit = _REG.get(row_nzr.data_ptr())
+    if hit is not None:
+        return hit[1]
+    host = row_nzr[:Header.WORDS].cpu().contiguous()
+    h = Header.from_buffer_copy(host.numpy().tobytes())
+    if num_nodes is not None and check(lib().hcspmm_plan_check(ctypes.byref(h), num_nodes, num_edges), soft=True) != 0:
+        return None
+    if h.magic != Header.MAGIC:
+        return None
+    _register(row_nzr, h)
+    return h
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr() if t is not None and t.numel() > 0 else 0)
+
+
+def _i32_host(t):
+    return t.detach().to(device="cpu", dtype=torch.int32).contiguous()
+
+
+def preprocess(column_index, row_pointers, num_nodes, num_edges, num_row_windows, rule=None):
+    """HCSPMM.preprocess (hybrid_all.cpp:13-17,501; hybrid_all_kernel.cu:339-408).
+
+    Argument order as the reference: column_index FIRST (HC-SpMM_main.py:52).  `num_edges` is
+    ignored in favour of column_index.size(0).  Runs on the host (north_star),
+    returns [blockPartition, edgeToColumn, edgeToRow, hybrid_type, row_nzr, col_nzr] on the device
+    of `column_index`; `row_nzr` carries the MI355X launch plan, `col_nzr` stays the [0] placeholder.
+    """
+    L = lib()
+    dev = column_index.device
+    col_h = _i32_host(column_index)
+    rp_h = _i32_host(row_pointers)
+    N = int(rp_h.numel()) - 1
+    E = int(col_h.numel())
+    if int(num_nodes) != N:
+        raise RuntimeError("preprocess: num_nodes (%d) != row_pointers.size(0)-1 (%d)" % (num_nodes, N))
+    W = (N + 15) // 16
+    if int(num_row_windows) != W:
+        raise RuntimeError("preprocess: num_row_windows (%d) != ceil(N/16) (%d)" % (num_row_windows, W))
+    bp = torch.zeros(W, dtype=torch.int32)
+    ht = torch.zeros(W, dtype=torch.int32)
+    e2c = torch.zeros(E, dtype=torch.int32)
+    e2r = torch.zeros(E, dtype=torch.int32)
+    r = _DEFAULT_RULE if rule is None else int(rule)
+    check(L.hcspmm_preprocess_host(_ptr(rp_h), _ptr(col_h), N, E, r, 0, _ptr(bp), _ptr(e2c), _ptr(e2r), _ptr(ht)))
+    words = ctypes.c_int64(0)
+    check(L.hcspmm_plan_words(_ptr(rp_h), N, E, _ptr(bp), _ptr(ht), ctypes.byref(_PLAN_PARAMS), ctypes.byref(words)))
+    plan = torch.zeros(max(int(words.value), Header.WORDS), dtype=torch.int32)
+    check(L.hcspmm_plan_build(_ptr(rp_h), _ptr(col_h), N, E, _ptr(bp), _ptr(e2c), _ptr(ht),
+                              ctypes.byref(_PLAN_PARAMS), _ptr(plan), plan.numel()))
+    h = Header.from_buffer_copy(plan[:Header.WORDS].numpy().tobytes())
+    outs = [t.to(dev) for t in (bp, e2c, e2r, ht, plan)]
+    _register(outs[4], h)
+    col_nzr = torch.zeros(1, dtype=torch.int32, device=dev)
+    return [outs[0], outs[1], outs[2], outs[3], outs[4], col_nzr]
+
+
+def _check_input(t, name):
+    # hybrid_all.cpp:185-187 CHECK_CUDA / CHECK_CONTIGUOUS, same messages
+    if not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA tensor" % name)
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)
+
+
+def _graph_args(X, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, hybrid_type, row_nzr,
+                rect=False):
+    for t, n in ((X, "input"), (row_pointers, "nodePointer"), (column_index, "edgeList"),
+                 (blockPartition, "blockPartition"), (edgeToColumn, "edgeToColumn"), (edgeToRow, "edgeToRow")):
+        _check_input(t, n)
+    if X.dtype != torch.float32 or X.dim() != 2:
+        raise RuntimeError("input must be a 2-D float32 tensor")
+    N = row_pointers.size(0) - 1
+    E = column_index.size(0)
+    D = X.size(1)
+    if X.size(0) != N and not rect:
+        raise RuntimeError("input has %d rows but the graph has %d nodes" % (X.size(0), N))
+    h = plan_header(row_nzr, N, E) if (row_nzr is not None and row_nzr.is_cuda) else None
+    return N, E, D, h
+
+
+def _spmm(X, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, hybrid_type, row_nzr, col_nzr,
+          Z=None, rect=False):
+    L = lib()
+    N, E, D, h = _graph_args(X, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, hybrid_type,
+                             row_nzr, rect)
+    if Z is None:
+        Z = torch.empty((N, D), dtype=torch.float32, device=X.device)
+    ws, ws_bytes = None, 0
+    if h is not None:
+        ws_bytes = int(L.hcspmm_workspace_bytes(ctypes.byref(h), D))
+        if ws_bytes:
+            ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=X.device)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(X.device).cuda_stream)
+    with torch.cuda.device(X.device):
+        check(L.hcspmm_forward(_ptr(X), _ptr(Z), _ptr(row_pointers), _ptr(column_index), _ptr(blockPartition),
+                               _ptr(edgeToColumn), _ptr(edgeToRow), _ptr(hybrid_type),
+                               _ptr(row_nzr) if h is not None else ctypes.c_void_p(0),
+                               ctypes.byref(h) if h is not None else None, N, E, D, _ptr(ws), ws_bytes, stream))
+    return Z
+
+
+def forward(X, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, hybrid_type, row_nzr, col_nzr):
+    """HCSPMM.forward -> [A*X]  (hybrid_all.cpp:194-221; any embedding_dim)."""
+    return [_spmm(X, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, hybrid_type, row_nzr, col_nzr)]
+
+
+def forward_rect(X_full, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, hybrid_type, row_nzr,
+                 col_nzr):
+    """Row-block form used by the multi-GPU shard (hcspmm.sharded): A is n_local x M with column ids
+    indexing the rows of X_full (M x D, the all-gathered embedding matrix) -> [Z_local (n_local x D)]."""
+    return [_spmm(X_full, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, hybrid_type, row_nzr,
+                  col_nzr, rect=True)]
+
+
+# The reference's dim-specialised variants compute the same product (hybrid_all.cpp:223-308);
+# forward_fixed32 silently truncated to 32 columns for D > 32 -- not reproduced.
+forward_more = forward
+forward_fixed32 = forward
+forward_fixed64 = forward
+
+
+def _fused(X, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, hybrid_type, row_nzr, col_nzr,
+           weights, output=None):
+    L = lib()
+    N, E, D, h = _graph_args(X, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, hybrid_type,
+                             row_nzr)
+    if not weights.is_cuda or weights.dtype != torch.float32 or weights.dim() != 2 or weights.size(0) != D:
+        raise RuntimeError("weights must be a CUDA float32 tensor of shape [embedding_dim, hidden_dim]")
+    H = weights.size(1)
+    if output is None:
+        output = torch.empty((N, H), dtype=torch.float32, device=X.device)
+    else:
+        _check_input(output, "output")
+        if output.dtype != torch.float32 or output.numel() != N * H:
+            raise RuntimeError("output must be float32 with num_nodes*hidden_dim elements")
+    out2 = torch.empty((N, D), dtype=torch.float32, device=X.device)
+    ws, ws_bytes = None, 0
+    if h is not None:
+        ws_bytes = int(L.hcspmm_workspace_bytes(ctypes.byref(h), D))
+        if ws_bytes:
+            ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=X.device)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(X.device).cuda_stream)
+    with torch.cuda.device(X.device):
+        check(L.hcspmm_forward_fused(_ptr(X), _ptr(output), _ptr(out2), _ptr(weights), weights.stride(0),
+                                     weights.stride(1), H, _ptr(row_pointers), _ptr(column_index),
+                                     _ptr(blockPartition), _ptr(edgeToColumn), _ptr(edgeToRow), _ptr(hybrid_type),
+                                     _ptr(row_nzr) if h is not None else ctypes.c_void_p(0),
+                                     ctypes.byref(h) if h is not None else None, N, E, D, _ptr(ws), ws_bytes, stream))
+    return [output, out2]
+
+
+def forward_fixed32_fused(X, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, hybrid_type, row_nzr,
+                          col_nzr, weights):
+    """-> [(A*X)*weights, A*X]  (hybrid_all.cpp:310-339).  `weights` may be a transposed view."""
+    return _fused(X, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, hybrid_type, row_nzr, col_nzr,
+                  weights)
+
+
+forward_fixed64_fused = forward_fixed32_fused
+forward_GIN_final_fused = forward_fixed32_fused
+
+
+def forward_final_fused(X, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, hybrid_type, row_nzr,
+                        col_nzr, weights, output):
+    """-> [output (the caller's tensor, written in place), A*X]  (hybrid_all.cpp:405-435)."""
+    return _fused(X, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, hybrid_type, row_nzr, col_nzr,
+                  weights, output)
+
+
+forward_final_fused_64 = forward_final_fused
+
+# hybrid_all.cpp:516-523: every backward* name is bound to the matching forward function.
+backward = forward
+backward_fixed32 = forward_fixed32
+backward_fixed32_fused = forward_fixed32_fused
+backward_final_fused = forward_final_fused
+backward_fixed64 = forward_fixed64
+backward_fixed64_fused = forward_fixed64_fused
+backward_final_fused_64 = forward_final_fused_64
+backward_GIN_final_fused = forward_GIN_final_fused
+
+
+def loi_reorder(row_pointers, column_index):
+    """LOI layout reorder (LOI.cpp:660-805 + main's output order) -> (perm[N], group_sizes)."""
+    L = lib()
+    rp = _i32_host(row_pointers)
+    col = _i32_host(column_index)
+    N, E = rp.numel() - 1, col.numel()
+    perm = torch.empty(N, dtype=torch.int32)
+    gs = torch.empty(max(N, 1), dtype=torch.int32)
+    ng = ctypes.c_int64(0)
+    check(L.hcspmm_loi_reorder(_ptr(rp), _ptr(col), N, E, _ptr(perm), _ptr(gs), ctypes.byref(ng)))
+    return perm, gs[:ng.value].clone()
+
+
+def apply_permutation(row_pointers, column_index, perm):
+    """Relabel a CSR graph with a LOI permutation -> (row_pointers', column_index')."""
+    L = lib()
+    rp = _i32_host(row_pointers)
+    col = _i32_host(column_index)
+    p = _i32_host(perm)
+    N, E = rp.numel() - 1, col.numel()
+    rp2 = torch.empty(N + 1, dtype=torch.int32)
+    col2 = torch.empty(E, dtype=torch.int32)
+    check(L.hcspmm_apply_permutation(_ptr(rp), _ptr(col), N, E, _ptr(p), _ptr(rp2), _ptr(col2)))
+    return rp2, col2

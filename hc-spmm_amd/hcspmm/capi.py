@@ -1,0 +1,76 @@
+"""ctypes binding of libhcspmm.so -- one declaration per symbol of include/hcspmm.h."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "csrc", "libhcspmm.so"))
+
+RULE_INTENDED = 0
+RULE_INTENDED_GUARD = 1
+RULE_AS_SHIPPED = 2
+
+OK, EINVAL, ENOMEM, EPLAN, EHIP, EWORKSPACE, ERANGE = 0, -1, -2, -3, -4, -5, -6
+
+
+class Header(ctypes.Structure):
+    """hcspmm_plan_header (include/hcspmm.h)."""
+    WORDS = 32
+    MAGIC = 0x48435350
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "magic", "version", "total_words", "num_nodes", "num_edges", "num_windows", "split_threshold", "segment_len",
+        "n_tasks", "n_dense", "n_split_rows", "n_partials", "off_tasks", "off_dense_index", "off_dense_pack",
+        "off_fixups", "nnz_sparse", "nnz_dense", "uniq_dense", "max_dense_k")] + [("reserved", ctypes.c_int32 * 12)]
+
+
+class PlanParams(ctypes.Structure):
+    """hcspmm_plan_params."""
+    _fields_ = [("split_threshold", ctypes.c_int32), ("segment_len", ctypes.c_int32)]
+
+
+# every exported symbol of include/hcspmm.h: name -> (restype, argtypes)
+_vp, _i64, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
+_hp, _pp = ctypes.POINTER(Header), ctypes.POINTER(PlanParams)
+SYMBOLS = {
+    "hcspmm_strerror": (ctypes.c_char_p, [_int]),
+    "hcspmm_abi_version": (_int, []),
+    "hcspmm_last_hip_error": (_int, []),
+    "hcspmm_preprocess_host": (_int, [_vp, _vp, _i64, _i64, _int, _int, _vp, _vp, _vp, _vp]),
+    "hcspmm_plan_words": (_int, [_vp, _i64, _i64, _vp, _vp, _pp, ctypes.POINTER(_i64)]),
+    "hcspmm_plan_build": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _pp, _vp, _i64]),
+    "hcspmm_plan_check": (_int, [_hp, _i64, _i64]),
+    "hcspmm_workspace_bytes": (_sz, [_hp, _int]),
+    "hcspmm_forward": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _hp, _i64, _i64, _int, _vp, _sz, _vp]),
+    "hcspmm_forward_fused": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _hp,
+                                    _i64, _i64, _int, _vp, _sz, _vp]),
+    "hcspmm_loi_reorder": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, ctypes.POINTER(_i64)]),
+    "hcspmm_apply_permutation": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+}
+
+_LIB = None
+
+
+def lib():
+    """Load libhcspmm.so (built in-tree by hc-spmm_amd/csrc/Makefile).  Fails loudly when absent:
+    there is no CPU or PyTorch fallback for the hot path."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libhcspmm.so not found at %s -- run `python -c 'import __graft_entry__ as g; "
+                               "g.build()'` (or make -C hc-spmm_amd/csrc); no fallback path exists" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(rc, soft=False):
+    if rc != 0 and not soft:
+        L = lib()
+        msg = L.hcspmm_strerror(rc).decode()
+        if rc == EHIP:
+            msg += " (hipError_t %d)" % L.hcspmm_last_hip_error()
+        raise RuntimeError("hcspmm: %s [code %d]" % (msg, rc))
+    return rc

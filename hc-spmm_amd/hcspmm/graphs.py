@@ -1,0 +1,145 @@
+"""Synthetic graphs for tests and bench.py (there is no dataset in the image: the reference's
+Dataset.zip is missing).  All generators are seeded, return int32 CSR arrays
+(row_pointers[N+1], column_index[E]) with columns ascending and unique per row -- the invariants
+scipy's coo->csr gives the reference (dataset.py:95-96) -- and have no self loops.
+"""
+import numpy as np
+import scipy.sparse as sp
+
+
+def _to_csr(rows, cols, N):
+    """Binary CSR from (possibly duplicated) coordinate lists; duplicates merged like scipy tocsr()."""
+    keep = rows != cols
+    rows, cols = rows[keep], cols[keep]
+    m = sp.coo_matrix((np.ones(rows.shape[0], np.int8), (rows, cols)), shape=(N, N)).tocsr()
+    m.sum_duplicates()
+    m.sort_indices()
+    return m.indptr.astype(np.int32), m.indices.astype(np.int32)
+
+
+def powerlaw_graph(num_nodes, num_edges, seed=0, exponent=2.1, symmetric=True, shuffle=True, max_degree_frac=0.02):
+    """Chung-Lu style power-law graph with ~num_edges stored entries (directed count).
+
+    Endpoint weights w_i ~ (i + i0)^(-1/(exponent-1)); hubs are capped at max_degree_frac*N
+    expected degree; vertex ids are shuffled so hubs are spread over the row windows.
+    """
+    rng = np.random.default_rng(seed)
+    N = int(num_nodes)
+    alpha = 1.0 / (exponent - 1.0)
+    w = (np.arange(N, dtype=np.float64) + 1.0) ** (-alpha)
+    w /= w.sum()
+    if max_degree_frac is not None:
+        cap = max_degree_frac * N / max(num_edges, 1)
+        for _ in range(8):
+            w = np.minimum(w, cap)
+            w /= w.sum()
+    cdf = np.cumsum(w)
+    cdf[-1] = 1.0
+    target = int(num_edges)
+    pairs = target // 2 if symmetric else target
+    have_r = np.empty(0, np.int64)
+    have_c = np.empty(0, np.int64)
+    perm = rng.permutation(N) if shuffle else np.arange(N)
+    for _ in range(6):
+        need = pairs - (have_r.shape[0] // (2 if symmetric else 1))
+        if need <= 0:
+            break
+        draw = int(need * 1.15) + 16
+        a = np.searchsorted(cdf, rng.random(draw)).astype(np.int64)
+        b = np.searchsorted(cdf, rng.random(draw)).astype(np.int64)
+        ok = a != b
+        a, b = perm[a[ok]], perm[b[ok]]
+        if symmetric:
+            r = np.concatenate([have_r, a, b])
+            c = np.concatenate([have_c, b, a])
+        else:
+            r = np.concatenate([have_r, a])
+            c = np.concatenate([have_c, b])
+        key = np.unique(r * N + c)
+        have_r, have_c = key // N, key % N
+    if symmetric:
+        # trim symmetric pairs to the target (keep both directions of a pair together)
+        up = have_r < have_c
+        ur, uc = have_r[up], have_c[up]
+        if ur.shape[0] > pairs:
+            sel = rng.choice(ur.shape[0], pairs, replace=False)
+            ur, uc = ur[sel], uc[sel]
+        have_r, have_c = np.concatenate([ur, uc]), np.concatenate([uc, ur])
+    elif have_r.shape[0] > target:
+        sel = rng.choice(have_r.shape[0], target, replace=False)
+        have_r, have_c = have_r[sel], have_c[sel]
+    return _to_csr(have_r, have_c, N)
+
+
+def uniform_graph(num_nodes, num_edges, seed=0):
+    """Erdos-Renyi style directed graph with ~num_edges entries."""
+    rng = np.random.default_rng(seed)
+    N = int(num_nodes)
+    r = rng.integers(0, N, int(num_edges * 1.05) + 8)
+    c = rng.integers(0, N, r.shape[0])
+    key = np.unique(r.astype(np.int64) * N + c)
+    key = key[(key // N) != (key % N)]
+    if key.shape[0] > num_edges:
+        key = rng.choice(key, int(num_edges), replace=False)
+    return _to_csr(key // N, key % N, N)
+
+
+def planted_dense_graph(num_nodes, seed=0, dense_fraction=0.7, cols_per_window=(8, 24), fill=0.5, sparse_degree=12):
+    """Graph whose 16-row windows mostly share a small column set (the layout LOI produces), so the
+    classifier sends a large share of windows to the dense-tile path (BASELINE config 5 analogue).
+
+    A `dense_fraction` of the windows draw K in cols_per_window shared columns and each row links
+    to each of them with probability `fill`; the other windows get `sparse_degree` random columns
+    per row (sparse-row path).
+    """
+    rng = np.random.default_rng(seed)
+    N = int(num_nodes)
+    W = (N + 15) // 16
+    rows, cols = [], []
+    is_dense = rng.random(W) < dense_fraction
+    for w in range(W):
+        r0, r1 = w * 16, min(w * 16 + 16, N)
+        nr = r1 - r0
+        if is_dense[w]:
+            K = int(rng.integers(cols_per_window[0], cols_per_window[1] + 1))
+            cset = rng.choice(N, K, replace=False)
+            mask = rng.random((nr, K)) < fill
+            rr, kk = np.nonzero(mask)
+            rows.append(r0 + rr)
+            cols.append(cset[kk])
+        else:
+            rr = np.repeat(np.arange(r0, r1), sparse_degree)
+            rows.append(rr)
+            cols.append(rng.integers(0, N, rr.shape[0]))
+    return _to_csr(np.concatenate(rows).astype(np.int64), np.concatenate(cols).astype(np.int64), N)
+
+
+def planted_dense_graph_fast(num_nodes, seed=0, dense_fraction=0.7, k_cols=16, fill=0.5, sparse_degree=12):
+    """Vectorised variant of planted_dense_graph for multi-million-node benchmarks (fixed K)."""
+    rng = np.random.default_rng(seed)
+    N = int(num_nodes)
+    W = (N + 15) // 16
+    is_dense = rng.random(W) < dense_fraction
+    dw = np.nonzero(is_dense)[0]
+    sw = np.nonzero(~is_dense)[0]
+    cset = rng.integers(0, N, (dw.shape[0], k_cols))                 # shared columns per dense window
+    m = rng.random((dw.shape[0], 16, k_cols)) < fill
+    wi, ri, ki = np.nonzero(m)
+    drow = dw[wi] * 16 + ri
+    dcol = cset[wi, ki]
+    ok = drow < N
+    srow = np.repeat(sw * 16, 16 * sparse_degree) + np.tile(np.repeat(np.arange(16), sparse_degree), sw.shape[0])
+    ok2 = srow < N
+    scol = rng.integers(0, N, srow.shape[0])
+    rows = np.concatenate([drow[ok], srow[ok2]]).astype(np.int64)
+    cols = np.concatenate([dcol[ok], scol[ok2]]).astype(np.int64)
+    return _to_csr(rows, cols, N)
+
+
+def write_coo_text(path, rowptr, col):
+    """Reference on-disk format: one "dst,src" line per entry, 1-based, sorted by src
+    (dataset.py:52-53 reads it; LOI.cpp:493-499 needs the second field ascending)."""
+    with open(path, "w") as f:
+        for r in range(len(rowptr) - 1):
+            for e in range(rowptr[r], rowptr[r + 1]):
+                f.write("%d,%d\n" % (col[e] + 1, r + 1))

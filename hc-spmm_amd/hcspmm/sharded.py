@@ -1,0 +1,100 @@
+"""Row-block sharding of the hybrid SpMM over the GPUs of one node (new design --
+the reference is single-GPU, HC-SpMM_main.py:47-49,113).
+
+Rank p owns a contiguous, window-aligned, nnz-balanced block of rows: A[rows_p, :] (columns stay
+global), X[rows_p, :] and Z[rows_p, :].  One exchange step per SpMM: an all-gather of the X row
+blocks (RCCL over xGMI when the backend is "nccl"); no reduction is needed because the output is
+row-sharded.  Blocks are padded to a common height so the gather is a single
+all_gather_into_tensor; global column ids are remapped once, on the host, to rows of the padded
+gathered matrix.  The local product is whatever callable the caller supplies -- the HIP operator
+in production (hcspmm.forward); CPU tests inject the oracle -- so this module contains no compute.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def partition_rows(row_pointers, world_size, align=16):
+    """Contiguous row ranges [(r0, r1)] * world_size, boundaries multiples of `align` (row windows
+    are never cut), balanced by stored entries + rows."""
+    rp = np.asarray(row_pointers, dtype=np.int64)
+    N = len(rp) - 1
+    W = (N + align - 1) // align
+    wstart = np.minimum(np.arange(W + 1) * align, N)
+    cost = rp[wstart] + wstart  # entries + rows before each window boundary
+    total = cost[-1]
+    cuts = [0]
+    for p in range(1, world_size):
+        w = int(np.searchsorted(cost, total * p / world_size, side="left"))
+        cuts.append(max(cuts[-1], min(w, W)))
+    cuts.append(W)
+    return [(int(wstart[cuts[p]]), int(wstart[cuts[p + 1]])) for p in range(world_size)]
+
+
+class ShardedGraph:
+    """The local row block of a CSR graph plus the column remap into the padded gathered X."""
+
+    def __init__(self, row_pointers, column_index, ranges, rank):
+        rp = np.asarray(row_pointers, dtype=np.int64)
+        col = np.asarray(column_index, dtype=np.int64)
+        self.ranges = list(ranges)
+        self.rank = rank
+        self.world_size = len(self.ranges)
+        self.r0, self.r1 = self.ranges[rank]
+        self.n_local = self.r1 - self.r0
+        self.pad_rows = max(r1 - r0 for r0, r1 in self.ranges)
+        e0, e1 = rp[self.r0], rp[self.r1]
+        self.row_pointers = (rp[self.r0:self.r1 + 1] - e0).astype(np.int32)
+        self.column_index = self.remap_columns(col[e0:e1]).astype(np.int32)
+
+    def remap_columns(self, cols):
+        """global vertex id -> row of the padded gathered matrix (owner * pad_rows + local index)."""
+        starts = np.array([r[0] for r in self.ranges], dtype=np.int64)
+        owner = np.searchsorted(starts, cols, side="right") - 1
+        return owner * self.pad_rows + (cols - starts[owner])
+
+    @classmethod
+    def from_local_block(cls, row_pointers_local, column_index_global, n_local, world_size, rank):
+        """Equal-height blocks (weak-scaling benchmarks): every rank holds n_local rows, columns are
+        global ids in [0, world_size * n_local); no padding, no remap needed."""
+        g = cls.__new__(cls)
+        g.ranges = [(p * n_local, (p + 1) * n_local) for p in range(world_size)]
+        g.rank, g.world_size = rank, world_size
+        g.r0, g.r1 = g.ranges[rank]
+        g.n_local = g.pad_rows = n_local
+        g.row_pointers = np.asarray(row_pointers_local, dtype=np.int32)
+        g.column_index = np.asarray(column_index_global, dtype=np.int32)
+        return g
+
+
+class ShardedSpMM:
+    """Z_local = A[rows_p, :] @ all_gather(X_local).
+
+    local_spmm(X_full[P*pad_rows, D]) -> Z_local[n_local, D] is the local operator.  With
+    n_panels > 1 the feature columns are cut into panels: the gather of panel k+1 runs on a side
+    stream while the product of panel k runs on the main stream (the gather and the product are of
+    the same order on xGMI vs HBM) -- used only on CUDA devices.
+    """
+
+    def __init__(self, graph, local_spmm, group=None):
+        self.g = graph
+        self.local_spmm = local_spmm
+        self.group = group
+
+    def gather(self, X_local):
+        g = self.g
+        D = X_local.shape[1]
+        if g.world_size == 1:
+            return X_local
+        if X_local.shape[0] != g.pad_rows:
+            pad = torch.zeros((g.pad_rows, D), dtype=X_local.dtype, device=X_local.device)
+            pad[:g.n_local] = X_local
+            X_local = pad
+        full = torch.empty((g.world_size * g.pad_rows, D), dtype=X_local.dtype, device=X_local.device)
+        dist.all_gather_into_tensor(full, X_local.contiguous(), group=self.group)
+        return full
+
+    def forward(self, X_local):
+        return self.local_spmm(self.gather(X_local))
+
+    __call__ = forward

@@ -1,0 +1,188 @@
+/*
+ * hcspmm.h -- C ABI of libhcspmm.so: MI355X-native (gfx950) hybrid SpMM for GNN
+ * aggregation, the drop-in for the hot path of ZJU-DAILY/HC-SpMM.
+ *
+ * Every entry point names the reference interface it replaces (file:line under
+ * the reference tree; "K.cu" = hybrid_kernel/hybrid_all_kernel.cu, "B.cpp" =
+ * hybrid_kernel/hybrid_all.cpp).  The ABI is plain C: raw pointers, sizes and a
+ * HIP stream; no torch types, no exceptions, no global mutable state.  All
+ * functions return HCSPMM_OK (0) or a negative code; hcspmm_strerror() names it.
+ *
+ * Pointer naming: *_h = host memory, *_d = device (HBM) memory.
+ * Index arrays are int32 (reference: dataset.py:102-103, K.cu:439-443); features
+ * are fp32 row-major.  A is binary: edge values are never read.
+ */
+#ifndef HCSPMM_H
+#define HCSPMM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HCSPMM_ABI_VERSION 1
+
+/* Row-window geometry: hybrid_kernel/config.h:4-5 (BLK_H 16, BLK_W 8). */
+#define HCSPMM_BLK_H 16
+#define HCSPMM_BLK_W 8
+
+/* return codes */
+#define HCSPMM_OK 0
+#define HCSPMM_EINVAL (-1)     /* bad argument (null pointer, negative size, D <= 0, ...) */
+#define HCSPMM_ENOMEM (-2)     /* host allocation failed */
+#define HCSPMM_EPLAN (-3)      /* plan blob does not match this graph / wrong magic or version */
+#define HCSPMM_EHIP (-4)       /* a HIP runtime call or kernel launch failed (hcspmm_last_hip_error) */
+#define HCSPMM_EWORKSPACE (-5) /* workspace smaller than hcspmm_workspace_bytes() */
+#define HCSPMM_ERANGE (-6)     /* a size exceeds what the int32 index contract can address */
+
+/* Window classifier rule. */
+#define HCSPMM_RULE_INTENDED 0       /* logit > 0 -> sparse-row(0) else dense-tile(1); paper p.7, K.cu:261 w/o guard */
+#define HCSPMM_RULE_INTENDED_GUARD 1 /* K.cu:261 literally: size > 32 || logit > 0 -> 0 */
+#define HCSPMM_RULE_AS_SHIPPED 2     /* K.cu:262 literally: float used as bool */
+
+const char* hcspmm_strerror(int code);
+int hcspmm_abi_version(void);
+/* hipError_t (as int) of the most recent failing HIP call on this thread, 0 if none. */
+int hcspmm_last_hip_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * preprocess (host).  Replaces `preprocess` K.cu:339-408 (binding B.cpp:13-17, :501) and its
+ * kernels fill_edgeToRow K.cu:314-326, fill_segment K.cu:289-301, thrust::sort K.cu:386-399,
+ * generate_edgetocolumn K.cu:242-269.  Integer outputs are bit-exact with the reference
+ * algorithm (Appendix A of SURVEY.md); empty windows get blockPartition = hybrid_type = 0.
+ *   row_pointers_h[N+1], column_index_h[E] : CSR, columns ascending & unique within a row
+ *   blockPartition_h[W], hybrid_type_h[W], edgeToColumn_h[E], edgeToRow_h[E] : outputs, W = ceil(N/16)
+ *   num_threads <= 0 : use all host cores.
+ * ---------------------------------------------------------------------------------------- */
+int hcspmm_preprocess_host(const int32_t* row_pointers_h, const int32_t* column_index_h, int64_t num_nodes,
+                           int64_t num_edges, int rule, int num_threads, int32_t* blockPartition_h,
+                           int32_t* edgeToColumn_h, int32_t* edgeToRow_h, int32_t* hybrid_type_h);
+
+/* ------------------------------------------------------------------------------------------
+ * Launch plan (host build, device resident).  New on MI355X: the reference branches per thread
+ * block on hybrid_type (K.cu:960,1039) with one block per window; here the host turns the
+ * classified windows into (a) length-sorted sparse-row tasks, long rows split into segments, and
+ * (b) packed dense-tile windows (sorted unique columns + 0/1 tile masks in MFMA lane order).
+ * The blob travels in the reference's reserved `row_nzr` tensor slot (K.cu:405: row_nzr/col_nzr
+ * are [0] placeholders that every forward receives and never reads).
+ *
+ * The first HCSPMM_PLAN_HEADER_WORDS int32 words of the blob are a hcspmm_plan_header; callers
+ * keep a host copy of it (hcspmm_forward needs the counts to size its grid without a device
+ * read-back).
+ * ---------------------------------------------------------------------------------------- */
+#define HCSPMM_PLAN_MAGIC 0x48435350 /* "HCSP" */
+#define HCSPMM_PLAN_VERSION 2
+#define HCSPMM_PLAN_HEADER_WORDS 32
+
+typedef struct hcspmm_plan_header {
+  int32_t magic;            /* HCSPMM_PLAN_MAGIC */
+  int32_t version;          /* HCSPMM_PLAN_VERSION */
+  int32_t total_words;      /* size of the whole blob in int32 words */
+  int32_t num_nodes;        /* N the plan was built for */
+  int32_t num_edges;        /* E the plan was built for */
+  int32_t num_windows;      /* W */
+  int32_t split_threshold;  /* rows with more entries than this are split ... */
+  int32_t segment_len;      /* ... into segments of this many entries */
+  int32_t n_tasks;          /* sparse-row tasks (one per whole row or row segment), length-sorted */
+  int32_t n_dense;          /* dense-tile windows */
+  int32_t n_split_rows;     /* rows whose partial sums are combined by the fix-up pass */
+  int32_t n_partials;       /* partial-sum slots (rows of the workspace) */
+  int32_t off_tasks;        /* word offsets of the sections inside the blob */
+  int32_t off_dense_index;
+  int32_t off_dense_pack;
+  int32_t off_fixups;
+  int32_t nnz_sparse;       /* entries handled by the sparse-row path */
+  int32_t nnz_dense;        /* entries handled by the dense-tile path */
+  int32_t uniq_dense;       /* sum of unique columns over dense windows (gathered X rows) */
+  int32_t max_dense_k;      /* largest padded K (8*blockPartition) among dense windows */
+  int32_t reserved[12];
+} hcspmm_plan_header;
+
+/* Tunables for the plan; zero-initialise for defaults. */
+typedef struct hcspmm_plan_params {
+  int32_t split_threshold; /* default 512 */
+  int32_t segment_len;     /* default 256 */
+} hcspmm_plan_params;
+
+/* Number of int32 words a plan for this graph needs (so the caller can allocate the tensor). */
+int hcspmm_plan_words(const int32_t* row_pointers_h, int64_t num_nodes, int64_t num_edges,
+                      const int32_t* blockPartition_h, const int32_t* hybrid_type_h,
+                      const hcspmm_plan_params* params, int64_t* words_out);
+
+/* Fill plan_h[words] (host).  The caller uploads it to HBM unchanged. */
+int hcspmm_plan_build(const int32_t* row_pointers_h, const int32_t* column_index_h, int64_t num_nodes,
+                      int64_t num_edges, const int32_t* blockPartition_h, const int32_t* edgeToColumn_h,
+                      const int32_t* hybrid_type_h, const hcspmm_plan_params* params, int32_t* plan_h,
+                      int64_t words);
+
+/* Validate a header against (N, E); HCSPMM_OK or HCSPMM_EPLAN. */
+int hcspmm_plan_check(const hcspmm_plan_header* header_h, int64_t num_nodes, int64_t num_edges);
+
+/* Bytes of device workspace hcspmm_forward* needs for this plan and embedding_dim (may be 0). */
+size_t hcspmm_workspace_bytes(const hcspmm_plan_header* header_h, int embedding_dim);
+
+/* ------------------------------------------------------------------------------------------
+ * forward: Z = A * X.  Replaces the launchers spmm_forward_plus K.cu:410-455,
+ * spmm_forward_plus_more :457-498, spmm_forward_plus_fixed32 :500-551, spmm_forward_plus_fixed64
+ * :553-594 (bindings B.cpp:194-308; Python names forward / forward_more / forward_fixed32 /
+ * forward_fixed64 and the backward* aliases B.cpp:516-523) and the kernels
+ * spmm_forward_cuda_kernel_arbi_warps_hybrid_{adaptive,adaptive_more,32,64} K.cu:919-1637.
+ * One entry point serves every embedding_dim (the fixed32/fixed64 variants are the same math).
+ *
+ *   X_d[N*D], Z_d[N*D]            fp32 row-major, Z fully overwritten
+ *   row_pointers_d .. hybrid_type_d   the 7 graph tensors of the reference API (device)
+ *   plan_d / plan_header_h        plan blob in HBM + host copy of its header, or both NULL:
+ *                                 then the plan-free kernel runs (one workgroup per row window,
+ *                                 branch on hybrid_type, as the reference does)
+ *   workspace_d / workspace_bytes >= hcspmm_workspace_bytes(); may be NULL when that is 0
+ *   stream                        hipStream_t (as void*); NULL = the null stream
+ * Asynchronous: returns after enqueueing; no host-device synchronisation inside.
+ * ---------------------------------------------------------------------------------------- */
+int hcspmm_forward(const float* X_d, float* Z_d, const int32_t* row_pointers_d, const int32_t* column_index_d,
+                   const int32_t* blockPartition_d, const int32_t* edgeToColumn_d, const int32_t* edgeToRow_d,
+                   const int32_t* hybrid_type_d, const int32_t* plan_d, const hcspmm_plan_header* plan_header_h,
+                   int64_t num_nodes, int64_t num_edges, int embedding_dim, void* workspace_d,
+                   size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused aggregate + update: out2 = A * X (N x D), out = out2 * weights (N x H), weights row-major
+ * D x H with row stride weights_ld_row and column stride weights_ld_col in elements (so a
+ * transposed view, GNN_model.py:98,120, needs no copy).  Replaces spmm_forward_plus_fixed32_fused
+ * K.cu:596-647, _fixed64_fused :649-697, _final_fused :699-755, _final_fused_64 :757-806,
+ * _GIN_final_fused :808-863 (bindings B.cpp:310-498) and their kernels K.cu:1639-2770.
+ * `out_d` may be a caller-owned buffer (forward_final_fused writes the caller's `output`).
+ * ---------------------------------------------------------------------------------------- */
+int hcspmm_forward_fused(const float* X_d, float* out_d, float* out2_d, const float* weights_d,
+                         int64_t weights_ld_row, int64_t weights_ld_col, int hidden_dim,
+                         const int32_t* row_pointers_d, const int32_t* column_index_d,
+                         const int32_t* blockPartition_d, const int32_t* edgeToColumn_d,
+                         const int32_t* edgeToRow_d, const int32_t* hybrid_type_d, const int32_t* plan_d,
+                         const hcspmm_plan_header* plan_header_h, int64_t num_nodes, int64_t num_edges,
+                         int embedding_dim, void* workspace_d, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LOI layout reorder (host).  Replaces reorder_plus_new_direct LOI.cpp:660-805 with the in-CSR
+ * construction and output ordering of its main (LOI.cpp:826-841, :873-891): perm_out_h[N] lists
+ * old vertex ids in their new order (full 16-row groups first, then short groups, then vertices
+ * with no out-edges).  Bit-identical output, without the reference's O(N^2/16) per-group bitmap
+ * reallocation (LOI.cpp:695) or its 18 269 000-vertex static limit (LOI.cpp:96).
+ *   group_sizes_out_h : optional [N] buffer receiving the group sizes in creation order;
+ *   n_groups_out      : optional.
+ * ---------------------------------------------------------------------------------------- */
+int hcspmm_loi_reorder(const int32_t* row_pointers_h, const int32_t* column_index_h, int64_t num_nodes,
+                       int64_t num_edges, int32_t* perm_out_h, int32_t* group_sizes_out_h,
+                       int64_t* n_groups_out);
+
+/* Apply a LOI permutation to a CSR graph (the step missing from the reference repository,
+ * SURVEY.md section 1 L0): new id of old vertex perm[i] is i; rows AND columns are relabelled,
+ * columns re-sorted ascending.  Outputs have the sizes of the inputs. */
+int hcspmm_apply_permutation(const int32_t* row_pointers_h, const int32_t* column_index_h, int64_t num_nodes,
+                             int64_t num_edges, const int32_t* perm_h, int32_t* row_pointers_out_h,
+                             int32_t* column_index_out_h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HCSPMM_H */

@@ -1,0 +1,243 @@
+"""CPU tests of the PRODUCT's host side (libhcspmm.so through its C ABI): exported symbols,
+preprocess / plan / LOI integer parity against the oracle and the reference-generated golden
+vectors, argument checking.  No device compute is called here."""
+import ctypes
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import hcspmm
+from hcspmm import graphs
+from hcspmm.capi import Header, PlanParams
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def _pre(rp, col, rule=0):
+    N = len(rp) - 1
+    return hcspmm.preprocess(_t(col), _t(rp), N, len(col), (N + 15) // 16, rule=rule)
+
+
+def test_library_exports_every_declared_symbol(capi):
+    header = open(os.path.join(ROOT, "include", "hcspmm.h")).read()
+    declared = set(re.findall(r"\b(hcspmm_[a-z0-9_]+)\s*\(", header))
+    declared -= {"hcspmm_plan_header", "hcspmm_plan_params"}
+    assert declared == set(capi.SYMBOLS), declared ^ set(capi.SYMBOLS)
+    L = capi.lib()
+    for name in declared:
+        assert getattr(L, name) is not None
+    assert L.hcspmm_abi_version() == 1
+    assert ctypes.sizeof(Header) == 4 * Header.WORDS
+
+
+def test_missing_library_fails_loudly(monkeypatch, capi):
+    monkeypatch.setattr(capi, "_LIB", None)
+    monkeypatch.setattr(capi, "LIB_PATH", "/nonexistent/libhcspmm.so")
+    with pytest.raises(RuntimeError, match="no fallback"):
+        capi.lib()
+
+
+GRAPHS = [
+    ("powerlaw_10k", lambda: graphs.powerlaw_graph(10000, 50000, seed=1)),       # BASELINE config 2 shape
+    ("powerlaw_ragged", lambda: graphs.powerlaw_graph(1003, 20000, seed=2)),      # N % 16 != 0, hubs
+    ("uniform", lambda: graphs.uniform_graph(2048, 30000, seed=3)),
+    ("planted", lambda: graphs.planted_dense_graph(1500, seed=4)),
+    ("empty", lambda: (np.zeros(50, np.int32), np.zeros(0, np.int32))),
+    ("single", lambda: (np.array([0, 1], np.int32), np.array([0], np.int32))),
+]
+
+
+@pytest.mark.parametrize("name,gen", GRAPHS, ids=[g[0] for g in GRAPHS])
+@pytest.mark.parametrize("rule", [0, 1, 2])
+def test_preprocess_bit_exact_vs_oracle(oracle_mod, name, gen, rule):
+    rp, col = gen()
+    want = oracle_mod.preprocess(rp, col, rule)
+    got = _pre(rp, col, rule)
+    for w, g, n in zip(want, got[:4], ("blockPartition", "edgeToColumn", "edgeToRow", "hybrid_type")):
+        assert g.dtype == torch.int32
+        assert np.array_equal(w, g.numpy()), n
+    assert got[5].tolist() == [0]  # col_nzr stays the reference's placeholder (hybrid_all_kernel.cu:405)
+
+
+def test_preprocess_multithreaded_equals_single(capi):
+    rp, col = graphs.powerlaw_graph(60000, 400000, seed=5)
+    N, E = len(rp) - 1, len(col)
+    W = (N + 15) // 16
+    outs = []
+    for threads in (1, 7):
+        bp, ht = np.zeros(W, np.int32), np.zeros(W, np.int32)
+        e2c, e2r = np.zeros(E, np.int32), np.zeros(E, np.int32)
+        rc = capi.lib().hcspmm_preprocess_host(rp.ctypes.data, col.ctypes.data, N, E, 0, threads, bp.ctypes.data,
+                                               e2c.ctypes.data, e2r.ctypes.data, ht.ctypes.data)
+        assert rc == 0
+        outs.append((bp, e2c, e2r, ht))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
+def test_preprocess_rejects_bad_arguments(capi):
+    L = capi.lib()
+    rp = np.array([0, 2, 1], np.int32)  # not monotone
+    col = np.array([0], np.int32)
+    out = np.zeros(4, np.int32)
+    assert L.hcspmm_preprocess_host(rp.ctypes.data, col.ctypes.data, 2, 1, 0, 1, out.ctypes.data, out.ctypes.data,
+                                    out.ctypes.data, out.ctypes.data) == capi.EINVAL
+    assert L.hcspmm_preprocess_host(None, None, 2, 1, 0, 1, None, None, None, None) == capi.EINVAL
+    rp = np.array([0, 1], np.int32)
+    assert L.hcspmm_preprocess_host(rp.ctypes.data, col.ctypes.data, 1, 1, 9, 1, out.ctypes.data, out.ctypes.data,
+                                    out.ctypes.data, out.ctypes.data) == capi.EINVAL  # unknown rule
+    with pytest.raises(RuntimeError, match="num_row_windows"):
+        hcspmm.preprocess(_t(col), _t(rp), 1, 1, 5)
+
+
+def _decode_plan(plan):
+    h = Header.from_buffer_copy(plan[:Header.WORDS].tobytes())
+    tasks = plan[h.off_tasks:h.off_tasks + 4 * h.n_tasks].reshape(-1, 4)
+    dindex = plan[h.off_dense_index:h.off_dense_index + 4 * h.n_dense].reshape(-1, 4)
+    fix = plan[h.off_fixups:h.off_fixups + 4 * h.n_split_rows].reshape(-1, 4)
+    return h, tasks, dindex, fix
+
+
+@pytest.mark.parametrize("name,gen", GRAPHS[:4], ids=[g[0] for g in GRAPHS[:4]])
+def test_plan_covers_every_entry_exactly_once(name, gen):
+    rp, col = gen()
+    N, E = len(rp) - 1, len(col)
+    bp, e2c, e2r, ht, plan_t, _ = _pre(rp, col, 0)
+    plan = plan_t.numpy()
+    h, tasks, dindex, fix = _decode_plan(plan)
+    assert h.magic == Header.MAGIC and h.num_nodes == N and h.num_edges == E and h.total_words == len(plan)
+    ht = ht.numpy()
+    cover = np.zeros(E, np.int32)
+    rows_written = np.zeros(N, np.int32)
+    # sparse tasks: sorted by descending length, each <= split_threshold
+    lens = tasks[:, 2]
+    assert np.all(np.diff(lens) <= 0) and (len(lens) == 0 or lens.max() <= h.split_threshold)
+    for row, e0, ln, slot in tasks:
+        assert ht[row // 16] == 0 or rp[min((row // 16) * 16 + 16, N)] == rp[(row // 16) * 16]
+        assert rp[row] <= e0 and e0 + ln <= rp[row + 1]
+        cover[e0:e0 + ln] += 1
+        if slot < 0:
+            assert e0 == rp[row] and ln == rp[row + 1] - rp[row]
+            rows_written[row] += 1
+    # fix-ups: consecutive slots, segments tile the row in order
+    slots = {}
+    for row, e0, ln, slot in tasks:
+        if slot >= 0:
+            slots[slot] = (row, e0, ln)
+    assert sorted(slots) == list(range(h.n_partials))
+    for row, s0, ns, _ in fix:
+        e = rp[row]
+        for s in range(s0, s0 + ns):
+            assert slots[s][0] == row and slots[s][1] == e
+            e += slots[s][2]
+        assert e == rp[row + 1] and rp[row + 1] - rp[row] > h.split_threshold
+        rows_written[row] += 1
+    # dense windows: U reproduces the sorted unique columns, masks reproduce the 0/1 tiles
+    pack = plan[h.off_dense_pack:]
+    for w, off, K4, _ in dindex:
+        assert ht[w] == 1
+        K = 4 * K4
+        assert K == 8 * bp.numpy()[w]
+        lo, hi = rp[w * 16], rp[min(w * 16 + 16, N)]
+        U = pack[off:off + K]
+        uniq = np.unique(col[lo:hi])
+        assert np.array_equal(U[:len(uniq)], uniq) and np.all(U[len(uniq):] == -1)
+        masks = pack[off + K:off + K + 2 * K4].view(np.uint64)
+        tile = np.zeros((16, K), np.int32)
+        for kk in range(K4):
+            for lane in range(64):
+                if (int(masks[kk]) >> lane) & 1:
+                    tile[lane & 15, 4 * kk + (lane >> 4)] = 1
+        want = np.zeros((16, K), np.int32)
+        for r in range(w * 16, min(w * 16 + 16, N)):
+            want[r - w * 16, np.searchsorted(uniq, col[rp[r]:rp[r + 1]])] = 1
+        assert np.array_equal(tile, want)
+        cover[lo:hi] += 1
+        rows_written[w * 16:min(w * 16 + 16, N)] += 1
+    assert np.all(cover == 1) and np.all(rows_written == 1)
+    assert h.nnz_sparse + h.nnz_dense == E
+
+
+def test_plan_splits_hub_rows(capi):
+    # one row with 2000 entries, threshold 512 / segment 256 -> 8 segments
+    N = 2100
+    deg = np.zeros(N, np.int64)
+    deg[7] = 2000
+    deg[100:200] = 3
+    rp = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    rng = np.random.default_rng(0)
+    col = np.concatenate([np.sort(rng.choice(N, d, replace=False)) for d in deg if d]).astype(np.int32)
+    plan = _pre(rp, col, 2)[4].numpy()
+    h, tasks, _, fix = _decode_plan(plan)
+    assert h.n_split_rows == 1 and h.n_partials == 8 and fix.tolist() == [[7, 0, 8, 0]]
+    assert tasks[:8, 2].tolist() == [256] * 7 + [208] or sorted(tasks[:8, 2].tolist(), reverse=True) == [256] * 7 + [208]
+    ws = capi.lib().hcspmm_workspace_bytes(ctypes.byref(h), 128)
+    assert ws == 8 * 128 * 4
+
+
+def test_plan_check_rejects_mismatch(capi):
+    rp, col = graphs.powerlaw_graph(500, 3000, seed=1)
+    plan = _pre(rp, col)[4].numpy()
+    h = Header.from_buffer_copy(plan[:Header.WORDS].tobytes())
+    L = capi.lib()
+    assert L.hcspmm_plan_check(ctypes.byref(h), len(rp) - 1, len(col)) == 0
+    assert L.hcspmm_plan_check(ctypes.byref(h), len(rp), len(col)) == capi.EPLAN
+    h.magic = 0
+    assert L.hcspmm_plan_check(ctypes.byref(h), len(rp) - 1, len(col)) == capi.EPLAN
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "loi_*.npz"))))
+def test_loi_reorder_matches_reference_golden(path):
+    g = np.load(path)
+    perm, sizes = hcspmm.loi_reorder(_t(g["row_pointers"]), _t(g["column_index"]))
+    assert np.array_equal(sizes.numpy(), g["group_sizes"])
+    assert np.array_equal(perm.numpy(), g["order"])
+
+
+def test_loi_reorder_matches_oracle_on_larger_graph():
+    from oracle import loi_oracle
+    rp, col = graphs.powerlaw_graph(3000, 20000, seed=21)
+    groups, visit = loi_oracle.reorder_new_direct(rp, col, len(rp) - 1)
+    perm, sizes = hcspmm.loi_reorder(_t(rp), _t(col))
+    assert np.array_equal(perm.numpy(), loi_oracle.final_order(groups, visit))
+    assert sizes.tolist() == [len(x) for x in groups]
+
+
+def test_apply_permutation_is_a_graph_isomorphism():
+    import scipy.sparse as sp
+    rp, col = graphs.powerlaw_graph(700, 5000, seed=6)
+    N = len(rp) - 1
+    perm, _ = hcspmm.loi_reorder(_t(rp), _t(col))
+    rp2, col2 = hcspmm.apply_permutation(_t(rp), _t(col), perm)
+    A = sp.csr_matrix((np.ones(len(col)), col, rp), shape=(N, N))
+    B = sp.csr_matrix((np.ones(len(col)), col2.numpy(), rp2.numpy()), shape=(N, N))
+    p = perm.numpy()
+    assert (A[p][:, p] != B).nnz == 0
+    for r in range(N):
+        assert np.all(np.diff(col2.numpy()[rp2[r]:rp2[r + 1]]) > 0)
+    # the reorder must not lose dense-path windows on a graph that has planted structure
+    rp3, col3 = graphs.planted_dense_graph(1600, seed=2)
+    shuffle = np.random.default_rng(0).permutation(1600).astype(np.int32)
+    rps, cols = hcspmm.apply_permutation(_t(rp3), _t(col3), _t(shuffle))
+    before = int(_pre(rps.numpy(), cols.numpy())[3].sum())
+    perm2, _ = hcspmm.loi_reorder(rps, cols)
+    rpr, colr = hcspmm.apply_permutation(rps, cols, perm2)
+    after = int(_pre(rpr.numpy(), colr.numpy())[3].sum())
+    assert after > before
+
+
+def test_forward_requires_gpu_tensors():
+    rp, col = graphs.powerlaw_graph(64, 200, seed=1)
+    bp, e2c, e2r, ht, rn, cn = _pre(rp, col)
+    X = torch.zeros(64, 8)
+    with pytest.raises(RuntimeError, match="input must be a CUDA tensor"):
+        hcspmm.forward(X, _t(rp), _t(col), bp, e2c, e2r, ht, rn, cn)

@@ -1,0 +1,227 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI of
+libhcspmm.so (via the hcspmm host glue, which only forwards device pointers), against the CPU
+oracle on the same seeded inputs.
+
+Bars (north_star): integer products bit-exact; A*X within 1e-5 relative fp32.  Written as:
+  * integer-valued X (X[i,:] = i, the reference's gen_test_tensor idea, GNN_model.py:13-23):
+    result must be EXACT (every partial sum is an integer < 2^24, so any order gives it);
+  * random X: |got - fp64 product| <= 1e-5 * sum_j |x_j| componentwise (oracle.check_spmm), and
+    BIT-IDENTICAL to the sequential CSR-order fp32 oracle whenever no row is split (both kernels
+    keep CSR order; fp32 MFMA is an exact k-ordered fma chain with 0/1 multipliers).
+"""
+import numpy as np
+import pytest
+import torch
+
+import hcspmm
+from hcspmm import graphs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU: no HIP device visible")
+    return torch.device("cuda:0")
+
+
+def _t(a, dev=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return t.to(dev) if dev is not None else t
+
+
+class Graph:
+    def __init__(self, rp, col, dev, rule=0, plan=True, force_type=None):
+        self.rp, self.col = rp, col
+        self.N, self.E = len(rp) - 1, len(col)
+        self.rp_d, self.col_d = _t(rp, dev), _t(col, dev)
+        outs = hcspmm.preprocess(self.col_d, self.rp_d, self.N, self.E, (self.N + 15) // 16, rule=rule)
+        self.bp, self.e2c, self.e2r, self.ht, self.row_nzr, self.col_nzr = outs
+        if force_type is not None:  # force every window onto one sub-path; the plan must be rebuilt for it
+            self.ht = torch.full_like(self.ht, force_type)
+            plan = False
+        if not plan:  # the reference's [0] placeholders -> plan-free kernel
+            self.row_nzr = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def args(self):
+        return (self.rp_d, self.col_d, self.bp, self.e2c, self.e2r, self.ht, self.row_nzr, self.col_nzr)
+
+    def forward(self, X, fn=None):
+        return (fn or hcspmm.forward)(X, *self.args())[0]
+
+
+def _check(oracle_mod, g, X_np, Z, exact_bits):
+    Z = Z.cpu().numpy()
+    ok, ratio = oracle_mod.check_spmm(Z, g.rp, g.col, X_np)
+    assert ok, "relative error %.3g x the 1e-5 bar" % ratio
+    if exact_bits:
+        ref = oracle_mod.spmm_f32(g.rp, g.col, X_np)
+        assert np.array_equal(Z, ref), "not bit-identical to the CSR-order fp32 oracle (max diff %g)" % np.abs(Z - ref).max()
+
+
+def test_mfma_operand_layout_single_tile(oracle_mod, dev):
+    """Pins the v_mfma_f32_16x16x4_f32 operand/accumulator maps on the box: one dense window with an
+    ASYMMETRIC 0/1 tile and X rows holding distinct integers per (row, column)."""
+    N = 32
+    rows = {0: [1, 17, 20], 3: [17], 5: [1, 2, 3, 20, 31], 15: [0], 9: [2, 31]}
+    deg = np.zeros(N, np.int64)
+    for r, c in rows.items():
+        deg[r] = len(c)
+    rp = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    col = np.concatenate([np.array(rows[r], np.int32) for r in sorted(rows)])
+    for D in (16, 64, 20):
+        X = (np.arange(N)[:, None] * 100 + np.arange(D)[None, :]).astype(np.float32)
+        for plan in (True, False):
+            g = Graph(rp, col, dev, plan=plan, force_type=1 if not plan else None)
+            if plan:
+                assert int(g.ht[0]) == 1  # tiny window -> dense-tile path under the intended rule
+            Z = g.forward(_t(X, dev)).cpu().numpy()
+            assert np.array_equal(Z, oracle_mod.spmm_f32(rp, col, X)), (D, plan)
+
+
+CASES = [
+    # name, generator, split-free?
+    ("cora_scale", lambda: graphs.powerlaw_graph(10000, 50000, seed=1), True),     # BASELINE config 2
+    ("ragged_hubs", lambda: graphs.powerlaw_graph(1003, 20000, seed=2, max_degree_frac=0.9), False),
+    ("uniform", lambda: graphs.uniform_graph(2048, 30000, seed=3), True),
+    ("planted_dense", lambda: graphs.planted_dense_graph(1500, seed=4), True),
+    ("one_node", lambda: (np.array([0, 1], np.int32), np.array([0], np.int32)), True),
+    ("no_edges", lambda: (np.zeros(50, np.int32), np.zeros(0, np.int32)), True),
+]
+
+
+@pytest.mark.parametrize("name,gen,split_free", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("D", [32, 128, 256, 16, 22, 7, 96])
+def test_forward_parity_planned(oracle_mod, dev, name, gen, split_free, D):
+    rp, col = gen()
+    g = Graph(rp, col, dev)
+    rng = np.random.default_rng(D)
+    X = rng.standard_normal((g.N, D)).astype(np.float32)
+    split_free = split_free and (np.diff(rp).max(initial=0) <= 512)
+    _check(oracle_mod, g, X, g.forward(_t(X, dev)), exact_bits=split_free)
+    Xi = np.tile((np.arange(g.N, dtype=np.float32) % 4093)[:, None], (1, D))
+    Zi = g.forward(_t(Xi, dev)).cpu().numpy()
+    assert np.array_equal(Zi, oracle_mod.spmm_f32(rp, col, Xi))
+
+
+@pytest.mark.parametrize("name,gen,split_free", CASES[:4], ids=[c[0] for c in CASES[:4]])
+@pytest.mark.parametrize("D", [32, 128, 22])
+@pytest.mark.parametrize("mode", ["placeholder", "all_sparse", "all_dense"])
+def test_forward_parity_plan_free(oracle_mod, dev, name, gen, split_free, D, mode):
+    """The reference calling convention with row_nzr = col_nzr = [0] (plan-free kernel), with the
+    classifier's types and with every window forced onto each sub-path."""
+    rp, col = gen()
+    force = {"placeholder": None, "all_sparse": 0, "all_dense": 1}[mode]
+    g = Graph(rp, col, dev, plan=False, force_type=force)
+    X = np.random.default_rng(1).standard_normal((g.N, D)).astype(np.float32)
+    _check(oracle_mod, g, X, g.forward(_t(X, dev)), exact_bits=True)  # no row is ever split here
+
+
+@pytest.mark.parametrize("rule", [0, 1, 2])
+def test_rules_and_aliases(oracle_mod, dev, rule):
+    rp, col = graphs.planted_dense_graph(800, seed=9)
+    g = Graph(rp, col, dev, rule=rule)
+    want = oracle_mod.preprocess(rp, col, rule)
+    for w, t in zip(want, (g.bp, g.e2c, g.e2r, g.ht)):
+        assert np.array_equal(w, t.cpu().numpy())
+    X = np.random.default_rng(2).standard_normal((g.N, 32)).astype(np.float32)
+    Xd = _t(X, dev)
+    ref = oracle_mod.spmm_f32(rp, col, X)
+    for fn in (hcspmm.forward, hcspmm.forward_more, hcspmm.forward_fixed32, hcspmm.forward_fixed64, hcspmm.backward,
+               hcspmm.backward_fixed32, hcspmm.backward_fixed64):
+        assert np.array_equal(g.forward(Xd, fn).cpu().numpy(), ref)
+
+
+def test_split_rows_are_deterministic_and_within_tolerance(oracle_mod, dev):
+    # star-heavy graph: a few rows with thousands of entries -> segments + fix-up pass
+    rp, col = graphs.powerlaw_graph(4000, 120000, seed=5, exponent=1.8, max_degree_frac=0.8)
+    assert np.diff(rp).max() > 1024
+    g = Graph(rp, col, dev)
+    h = hcspmm.plan_header(g.row_nzr)
+    assert h.n_split_rows > 0 and h.n_partials >= 2 * h.n_split_rows
+    X = np.random.default_rng(3).standard_normal((g.N, 128)).astype(np.float32)
+    Xd = _t(X, dev)
+    Z1 = g.forward(Xd)
+    Z2 = g.forward(Xd)
+    assert torch.equal(Z1, Z2)
+    _check(oracle_mod, g, X, Z1, exact_bits=False)
+    # rows that were not split are still bit-identical to the sequential oracle
+    ref = oracle_mod.spmm_f32(rp, col, X)
+    small = np.diff(rp) <= h.split_threshold
+    assert np.array_equal(Z1.cpu().numpy()[small], ref[small])
+
+
+@pytest.mark.parametrize("D,H", [(32, 32), (64, 64), (96, 22), (32, 7), (16, 40)])
+def test_fused_variants(oracle_mod, dev, D, H):
+    rp, col = graphs.powerlaw_graph(1200, 9000, seed=6)
+    g = Graph(rp, col, dev)
+    rng = np.random.default_rng(7)
+    X = rng.standard_normal((g.N, D)).astype(np.float32)
+    W = rng.standard_normal((D, H)).astype(np.float32)
+    want_out, want_out2 = oracle_mod.spmm_fused_f32(rp, col, X, W)
+    Xd, Wd = _t(X, dev), _t(W, dev)
+    scale = np.abs(want_out2).astype(np.float64) @ np.abs(W).astype(np.float64)
+    for fn in (hcspmm.forward_fixed32_fused, hcspmm.forward_fixed64_fused, hcspmm.forward_GIN_final_fused,
+               hcspmm.backward_fixed32_fused):
+        out, out2 = fn(Xd, *g.args(), Wd)
+        assert np.array_equal(out2.cpu().numpy(), want_out2)
+        assert np.all(np.abs(out.cpu().numpy().astype(np.float64) - want_out) <= 1e-5 * scale + 1e-30)
+    # transposed (non-contiguous) weights, as the reference's backward passes them (GNN_model.py:98,120)
+    Wt_d = _t(np.ascontiguousarray(W.T), dev).transpose(0, 1)
+    assert not Wt_d.is_contiguous()
+    out, out2 = hcspmm.forward_fixed32_fused(Xd, *g.args(), Wt_d)
+    assert np.all(np.abs(out.cpu().numpy().astype(np.float64) - want_out) <= 1e-5 * scale + 1e-30)
+    # final_fused writes the caller's output buffer and returns it
+    buf = torch.zeros(g.N, H, device=dev)
+    out, out2 = hcspmm.forward_final_fused(Xd, *g.args(), Wd, buf)
+    assert out.data_ptr() == buf.data_ptr()
+    assert np.all(np.abs(buf.cpu().numpy().astype(np.float64) - want_out) <= 1e-5 * scale + 1e-30)
+
+
+def test_error_behaviour(dev):
+    rp, col = graphs.powerlaw_graph(200, 900, seed=1)
+    g = Graph(rp, col, dev)
+    X = torch.zeros(g.N, 16, device=dev)
+    with pytest.raises(RuntimeError, match="input must be contiguous"):
+        hcspmm.forward(X.t().contiguous().t(), *g.args())
+    with pytest.raises(RuntimeError, match="nodePointer must be a CUDA tensor"):
+        hcspmm.forward(X, g.rp_d.cpu(), *g.args()[1:])
+    with pytest.raises(RuntimeError, match="rows"):
+        hcspmm.forward(torch.zeros(g.N + 1, 16, device=dev), *g.args())
+    # a plan built for another graph is refused (HCSPMM_EPLAN), not silently used
+    other = Graph(*graphs.powerlaw_graph(300, 900, seed=2), dev)
+    with pytest.raises(RuntimeError, match="plan"):
+        hcspmm.forward(X, g.rp_d, g.col_d, g.bp, g.e2c, g.e2r, g.ht, other.row_nzr, g.col_nzr)
+
+
+def test_reddit_scale_properties(oracle_mod, dev):
+    """BASELINE config 3 at full size (233K nodes / 11.6M entries, D = 128): too big for the scalar
+    oracle to be quick, so parity is checked through size-independent properties -- exact integer
+    checksums (X = 1 -> degrees; X[i,:] = i mod 1021), linearity, a fixed sample of rows against
+    the oracle, and run-to-run determinism."""
+    rp, col = graphs.powerlaw_graph(233000, 11600000, seed=3)
+    g = Graph(rp, col, dev)
+    N, D = g.N, 128
+    deg = np.diff(rp).astype(np.float32)
+    Z = g.forward(torch.ones(N, D, device=dev)).cpu().numpy()
+    assert np.array_equal(Z, np.tile(deg[:, None], (1, D)))
+    ids = (np.arange(N) % 1021).astype(np.float32)
+    Zi = g.forward(_t(np.tile(ids[:, None], (1, D)), dev)).cpu().numpy()
+    cs = np.concatenate([[0.0], np.cumsum(ids[col].astype(np.float64))])
+    want = cs[rp[1:]] - cs[rp[:-1]]
+    assert np.array_equal(Zi[:, 0], want.astype(np.float32)) and np.array_equal(Zi[:, 0], Zi[:, D - 1])
+    rng = np.random.default_rng(0)
+    X1 = torch.from_numpy(rng.standard_normal((N, D)).astype(np.float32)).to(dev)
+    X2 = torch.from_numpy(rng.standard_normal((N, D)).astype(np.float32)).to(dev)
+    Z1, Z2, Z12 = g.forward(X1), g.forward(X2), g.forward(X1 + 2 * X2)
+    lin = (Z12 - (Z1 + 2 * Z2)).abs().max().item() / Z12.abs().max().item()
+    assert lin < 1e-5
+    assert torch.equal(Z1, g.forward(X1))
+    # sampled rows vs the oracle (sub-graph made of the sampled rows only)
+    rows = rng.choice(N, 2000, replace=False)
+    sub_deg = np.diff(rp)[rows]
+    sub_rp = np.concatenate([[0], np.cumsum(sub_deg)]).astype(np.int32)
+    sub_col = np.concatenate([col[rp[r]:rp[r + 1]] for r in rows]).astype(np.int32)
+    ok, ratio = oracle_mod.check_spmm(Z1.cpu().numpy()[rows], sub_rp, sub_col, X1.cpu().numpy())
+    assert ok, ratio

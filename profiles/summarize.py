@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 CSV output (gpurun_out/prof/<pass>/...) into profiles/<round>/ and refresh
+profiles/traffic.json, which bench.py reads for roofline.traffic.
+
+  python profiles/summarize.py gpurun_out/prof profiles/r01 reddit_d128
+
+Passes expected under the input dir: trace (--kernel-trace --stats), fetch (--pmc FETCH_SIZE),
+write (--pmc WRITE_SIZE), l2 (--pmc TCC_HIT_sum TCC_MISS_sum) -- each its own run, as
+MI355X_MICROARCH.md prescribes (FETCH_SIZE and WRITE_SIZE do not fit one pass).
+Corrections applied (same guide, section HBM): counters are in KiB; on gfx950 FETCH_SIZE reports
+half of the bytes of wide coalesced reads -> doubled; WRITE_SIZE is exact for 16-B stores.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+
+def counters(d):
+    acc = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            acc[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+def main():
+    src, dst, key = sys.argv[1], sys.argv[2], sys.argv[3]
+    os.makedirs(dst, exist_ok=True)
+    out = {"key": key, "kernels": {}}
+    for f in glob.glob(os.path.join(src, "trace", "**", "*_kernel_stats.csv"), recursive=True):
+        shutil.copy(f, os.path.join(dst, "%s_kernel_stats.csv" % key))
+        for r in csv.DictReader(open(f)):
+            if "hcspmm" in r["Name"]:
+                out["kernels"][r["Name"]] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
+                                             "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"])}
+    pmc = {}
+    for p in ("fetch", "write", "l2"):
+        for (k, c), v in counters(os.path.join(src, p)).items():
+            if "hcspmm" in k:
+                pmc.setdefault(k, {})[c] = v
+    out["pmc_per_launch"] = pmc
+    main_k = [k for k in pmc if "hybrid" in k]
+    if main_k:
+        m = pmc[main_k[0]]
+        fetch_b = 2.0 * m.get("FETCH_SIZE", 0.0) * 1024.0
+        write_b = m.get("WRITE_SIZE", 0.0) * 1024.0
+        out["traffic_bytes_per_launch"] = fetch_b + write_b
+        out["fetch_bytes_corrected"] = fetch_b
+        out["write_bytes"] = write_b
+        if "TCC_HIT_sum" in m:
+            out["l2_hit_rate"] = m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"])
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic.json")
+        t = json.load(open(tpath)) if os.path.exists(tpath) else {}
+        t[key] = fetch_b + write_b
+        json.dump(t, open(tpath, "w"), indent=1, sort_keys=True)
+    json.dump(out, open(os.path.join(dst, "%s_summary.json" % key), "w"), indent=1, sort_keys=True)
+    print(json.dumps(out, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,169 @@
+"""GNN layers over the HCSPMM operators -- counterpart of the reference's GNN_model.py (class names
+and call conventions kept so HC-SpMM_main.py-style drivers run unchanged).
+
+Two layer families, each a torch.autograd.Function built by `_make_layer_function`:
+
+  update-then-aggregate (GCN):   Y = A (X W)        dX = (A dY) W^T      dW = X^T (A dY)
+  aggregate-then-update (GIN):   Y = (A X) W        dX = A (dY W^T)      dW = (A X)^T dY
+
+The backward pass aggregates with A, not A^T, as the reference does (symmetric graphs;
+GNN_model.py:98,120,181).  Which HCSPMM entry point each stage calls follows the reference:
+
+  class                       forward                                   backward
+  HCSPMMFunctionFirst         mm -> forward_fixed32          (:134-136)  forward_fixed32, mm, mm     (:150-160)
+  HCSPMMFunctionFixed32       mm -> forward_fixed32          (:87-89)    forward_fixed32_fused(W^T)  (:98-101)
+  HCSPMMFunctionFinal         mm -> forward                  (:110-111)  forward_final_fused(W^T, output) (:120-124)
+  HCSPMMFunction              mm -> forward                  (:67-69)    forward, mm, mm             (:76-80)
+  HCSPMMFunction_GINFirst     forward -> mm                  (:190-194)  mm, mm, forward             (:201-205)
+  HCSPMMFunction_GINFixed32   forward_fixed32_fused(W)       (:169)      mm, mm, forward_fixed32     (:178-181)
+  HCSPMMFunction_GINFinal     forward_GIN_final_fused(W)     (:215)      mm, mm, forward_fixed32     (:227-230)
+  HCSPMMFunction_SAG          forward_fixed32                (:39)       forward                     (:54)
+"""
+import math
+import time
+
+import torch
+
+try:
+    from tqdm import tqdm
+except Exception:  # pragma: no cover
+    def tqdm(x):
+        return x
+
+import HCSPMM
+
+HYGNN = HCSPMM  # HC-SpMM_main.py:52 still calls the extension by its earlier name
+
+N_GRAPH = 8  # row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, hybrid_type, row_nzr, col_nzr
+
+
+def gen_test_tensor(X_prime):
+    """Known-answer features: row i filled with the value i (reference GNN_model.py:13-23), so
+    (A X)[r, :] = sum of r's neighbour ids -- exact in fp32."""
+    n, d = X_prime.size(0), X_prime.size(1)
+    return torch.arange(n, dtype=torch.float32, device=X_prime.device).unsqueeze(1).expand(n, d).contiguous()
+
+
+def _make_layer_function(name, aggregate_first, fwd_agg, bwd_agg, fwd_fused=None, bwd_fused=None, takes_output=False):
+    """Build one autograd Function.  fwd_agg / bwd_agg name the HCSPMM A*X entry points; *_fused,
+    when given, name the fused aggregate+update entry point used instead of (A*X then mm)."""
+
+    def forward(ctx, X, weights, *rest):
+        graph, extra = rest[:N_GRAPH], rest[N_GRAPH:]
+        if aggregate_first:
+            if fwd_fused is not None:
+                out, agg = getattr(HCSPMM, fwd_fused)(X, *graph, weights)[:2]
+            else:
+                agg = getattr(HCSPMM, fwd_agg)(X, *graph)[0]
+                out = torch.mm(agg, weights)
+            ctx.save_for_backward(agg, weights, *graph)
+        else:
+            out = getattr(HCSPMM, fwd_agg)(torch.mm(X, weights), *graph)[0]
+            ctx.save_for_backward(X, weights, *graph, *extra)
+        return out
+
+    def backward(ctx, d_out):
+        saved = ctx.saved_tensors
+        kept, weights, graph, extra = saved[0], saved[1], saved[2:2 + N_GRAPH], saved[2 + N_GRAPH:]
+        d_out = d_out.contiguous()
+        if aggregate_first:  # kept = A X
+            d_agg = torch.mm(d_out, weights.transpose(0, 1))
+            d_w = torch.mm(kept.transpose(0, 1), d_out)
+            d_x = getattr(HCSPMM, bwd_agg)(d_agg, *graph)[0]
+        else:  # kept = X
+            if bwd_fused is not None:
+                d_x, d_agg = getattr(HCSPMM, bwd_fused)(d_out, *graph, weights.transpose(0, 1), *extra)[:2]
+            else:
+                d_agg = getattr(HCSPMM, bwd_agg)(d_out, *graph)[0]
+                d_x = torch.mm(d_agg, weights.transpose(0, 1))
+            d_w = torch.mm(kept.transpose(0, 1), d_agg)
+        return (d_x, d_w) + (None,) * (N_GRAPH + (1 if takes_output else 0))
+
+    return type(name, (torch.autograd.Function,), {"forward": staticmethod(forward), "backward": staticmethod(backward),
+                                                   "__doc__": "see module docstring"})
+
+
+HCSPMMFunction = _make_layer_function("HCSPMMFunction", False, "forward", "forward")
+HCSPMMFunctionFirst = _make_layer_function("HCSPMMFunctionFirst", False, "forward_fixed32", "forward_fixed32")
+HCSPMMFunctionFixed32 = _make_layer_function("HCSPMMFunctionFixed32", False, "forward_fixed32", None,
+                                             bwd_fused="forward_fixed32_fused")
+HCSPMMFunctionFinal = _make_layer_function("HCSPMMFunctionFinal", False, "forward", None,
+                                           bwd_fused="forward_final_fused", takes_output=True)
+HCSPMMFunction_GINFirst = _make_layer_function("HCSPMMFunction_GINFirst", True, "forward", "forward")
+HCSPMMFunction_GINFixed32 = _make_layer_function("HCSPMMFunction_GINFixed32", True, None, "forward_fixed32",
+                                                 fwd_fused="forward_fixed32_fused")
+HCSPMMFunction_GINFinal = _make_layer_function("HCSPMMFunction_GINFinal", True, None, "forward_fixed32",
+                                               fwd_fused="forward_GIN_final_fused")
+
+
+class HCSPMMFunction_SAG(torch.autograd.Function):
+    """Bare aggregation A*X (the --single_kernel path, reference GNN_model.py:26-57)."""
+
+    @staticmethod
+    def forward(ctx, X, *graph):
+        ctx.save_for_backward(*graph)
+        return HCSPMM.forward_fixed32(X, *graph)[0]
+
+    @staticmethod
+    def backward(ctx, d_out):
+        return (HCSPMM.forward(d_out.contiguous(), *ctx.saved_tensors)[0],) + (None,) * N_GRAPH
+
+
+class SAG(torch.nn.Module):
+    """Holds the graph tensors and times the aggregation kernel (reference GNN_model.py:236-262)."""
+
+    def __init__(self, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, hybrid_type, row_nzr,
+                 col_nzr):
+        super().__init__()
+        self.graph = (row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, hybrid_type, row_nzr,
+                      col_nzr)
+        (self.row_pointers, self.column_index, self.blockPartition, self.edgeToColumn, self.edgeToRow,
+         self.hybrid_type, self.row_nzr, self.col_nzr) = self.graph
+
+    def forward(self, X):
+        return HCSPMMFunction_SAG.apply(X, *self.graph)
+
+    def profile(self, X, num_rounds=200):
+        torch.cuda.synchronize()
+        start = time.perf_counter()
+        for _ in tqdm(range(num_rounds)):
+            HCSPMMFunction_SAG.apply(X, *self.graph)
+        torch.cuda.synchronize()
+        dur = time.perf_counter() - start
+        print("=> SAG profiling avg (ms): {:.3f}".format(dur * 1e3 / num_rounds))
+        print()
+        return dur * 1e3 / num_rounds
+
+
+class _Conv(torch.nn.Module):
+    """fixed: 1 = first layer, 0 = hidden layer, 2 = last layer (reference GNN_model.py:264-302)."""
+    first_fn = hidden_fn = last_fn = None
+    last_takes_output = False
+
+    def __init__(self, input_dim, output_dim, fixed=0):
+        super().__init__()
+        self.weights = torch.nn.Parameter(torch.randn(input_dim, output_dim))
+        self.fixed = fixed
+
+    def reset_parameters(self):
+        stdv = 1.0 / math.sqrt(self.weights.size(1))
+        self.weights.data.uniform_(-stdv, stdv)
+
+    def forward(self, X, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, hybrid_type, row_nzr,
+                col_nzr, output):
+        graph = (row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, hybrid_type, row_nzr, col_nzr)
+        if self.fixed == 0:
+            return self.hidden_fn.apply(X, self.weights, *graph)
+        if self.fixed == 2:
+            extra = (output,) if self.last_takes_output else ()
+            return self.last_fn.apply(X, self.weights, *graph, *extra)
+        return self.first_fn.apply(X, self.weights, *graph)
+
+
+class GCNConv(_Conv):
+    first_fn, hidden_fn, last_fn = HCSPMMFunctionFirst, HCSPMMFunctionFixed32, HCSPMMFunctionFinal
+    last_takes_output = True
+
+
+class GINConv(_Conv):
+    first_fn, hidden_fn, last_fn = HCSPMMFunction_GINFirst, HCSPMMFunction_GINFixed32, HCSPMMFunction_GINFinal

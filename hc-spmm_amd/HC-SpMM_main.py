@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""GCN / GIN training driver and single-kernel profiler over the HCSPMM operators -- counterpart
+of the reference's HC-SpMM_main.py (same eight flags, HC-SpMM_main.py:18-27, same printed lines
+"Prep. (ms)" :54 and "=> SAG profiling avg (ms)" GNN_model.py:261, same model shape :66-110, same
+schedule: 9 untimed warm-up epochs then --epochs timed ones, Adam lr 0.01, nll_loss :114-158).
+
+Run from this directory:  python HC-SpMM_main.py --dataset example --model gcn
+The graph is read from ./Dataset/<name>.txt ("dst,src" 1-based lines).
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+for _p in (HERE, os.path.join(HERE, "hybrid_kernel")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import HCSPMM  # noqa: E402  (the torch extension built in hybrid_kernel/)
+from config import BLK_H  # noqa: E402
+from dataset import HCSPMM_dataset  # noqa: E402
+from GNN_model import SAG, GCNConv, GINConv, tqdm  # noqa: E402
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument("--dataset", type=str, default="DD_A_our_3", help="dataset")
+    p.add_argument("--dim", type=int, default=96, help="input embedding dimension")
+    p.add_argument("--num_layers", type=int, default=6, help="num layers")
+    p.add_argument("--hidden", type=int, default=32, help="hidden dimension")
+    p.add_argument("--classes", type=int, default=22, help="number of output classes")
+    p.add_argument("--epochs", type=int, default=200, help="number of epoches")
+    p.add_argument("--model", type=str, default="gcn", help="GNN model", choices=["gcn", "gin"])
+    p.add_argument("--single_kernel", action="store_true", help="whether to profile a single SAG kernel")
+    return p.parse_args(argv)
+
+
+class Net(nn.Module):
+    """conv1 (first) -> ReLU -> dropout -> (num_layers - 2) x [hidden conv -> ReLU] -> conv2 (last)
+    -> log_softmax   (reference HC-SpMM_main.py:66-110)."""
+
+    def __init__(self, conv_cls, dataset, graph, output, hidden, num_layers):
+        super().__init__()
+        self.dataset, self.graph, self.output = dataset, graph, output
+        self.conv1 = conv_cls(dataset.num_features, hidden, 1)
+        self.hidden_layers = nn.ModuleList(conv_cls(hidden, hidden, 0) for _ in range(num_layers - 2))
+        self.conv2 = conv_cls(hidden, dataset.num_classes, 2)
+        self.relu = nn.ReLU()
+
+    def forward(self):
+        x = self.relu(self.conv1(self.dataset.x, *self.graph, self.output))
+        x = F.dropout(x, training=self.training)
+        for conv in self.hidden_layers:
+            x = self.relu(conv(x, *self.graph, self.output))
+        x = self.conv2(x, *self.graph, self.output)
+        return F.log_softmax(x, dim=1)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    print(args)
+    if not torch.cuda.is_available():
+        raise RuntimeError("HC-SpMM_main.py needs a GPU: the HCSPMM operators have no CPU path")
+    device = torch.device("cuda:0")
+    dataset = HCSPMM_dataset(os.path.join("./Dataset/", args.dataset + ".txt"), args.dim, args.classes,
+                             load_from_txt=True, device=device)
+    num_nodes, num_edges = dataset.num_nodes, dataset.num_edges
+    num_row_windows = (num_nodes + BLK_H - 1) // BLK_H
+    column_index = dataset.column_index.to(device)
+    row_pointers = dataset.row_pointers.to(device)
+    output = torch.zeros(num_nodes, args.hidden, device=device)
+
+    start = time.perf_counter()
+    blockPartition, edgeToColumn, edgeToRow, hybrid_type, row_nzr, col_nzr = HCSPMM.preprocess(
+        column_index, row_pointers, num_nodes, num_edges, num_row_windows)
+    torch.cuda.synchronize()
+    print("Prep. (ms):\t{:.3f}".format((time.perf_counter() - start) * 1e3))
+    graph = (row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, hybrid_type, row_nzr, col_nzr)
+
+    if args.single_kernel:
+        return SAG(*graph).profile(dataset.x)
+
+    conv_cls = GCNConv if args.model == "gcn" else GINConv
+    model = Net(conv_cls, dataset, graph, output, args.hidden, args.num_layers).to(device)
+    optimizer = torch.optim.Adam(model.parameters(), lr=0.01)
+
+    def train():
+        model.train()
+        optimizer.zero_grad()
+        loss = F.nll_loss(model()[:], dataset.y[:])
+        loss.backward()
+        optimizer.step()
+        return loss
+
+    for _ in range(1, 10):  # dry run
+        train()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loss = None
+    for _ in tqdm(range(1, args.epochs + 1)):
+        loss = train()
+    torch.cuda.synchronize()
+    print("Train (ms/epoch):\t{:.3f}\tfinal loss {:.4f}".format((time.perf_counter() - t0) * 1e3 / max(args.epochs, 1),
+                                                                 float(loss) if loss is not None else float("nan")))
+    return model
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,103 @@
+"""GPU tests of the torch extension module `HCSPMM` (hc-spmm_amd/hybrid_kernel), i.e. the reference's
+own Python-visible boundary (hybrid_all.cpp:500-525 there), against the oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from hcspmm import graphs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXT = os.path.join(ROOT, "hc-spmm_amd", "hybrid_kernel")
+
+
+@pytest.fixture(scope="module")
+def HCSPMM():
+    if EXT not in sys.path:
+        sys.path.insert(0, EXT)
+    import HCSPMM as m  # built in-tree by __graft_entry__.build(); fails loudly if absent
+    return m
+
+
+def test_module_surface_matches_reference(HCSPMM):
+    # every name bound in the reference's PYBIND11_MODULE (hybrid_all.cpp:500-525)
+    names = ["preprocess", "forward", "forward_more", "forward_fixed32", "forward_fixed32_fused", "forward_final_fused",
+             "forward_fixed64", "forward_fixed64_fused", "forward_final_fused_64", "forward_GIN_final_fused", "backward",
+             "backward_fixed32", "backward_fixed32_fused", "backward_final_fused", "backward_fixed64",
+             "backward_fixed64_fused", "backward_final_fused_64", "backward_GIN_final_fused"]
+    for n in names:
+        assert callable(getattr(HCSPMM, n)), n
+    import HYGNN  # the old module name used by HC-SpMM_main.py:52
+    assert HYGNN.preprocess is HCSPMM.preprocess or callable(HYGNN.preprocess)
+
+
+def test_cpu_input_is_rejected_with_reference_message(HCSPMM):
+    rp, col = graphs.powerlaw_graph(100, 400, seed=1)
+    outs = HCSPMM.preprocess(torch.from_numpy(col), torch.from_numpy(rp), 100, len(col), 7)
+    with pytest.raises(RuntimeError, match="input must be a CUDA tensor"):
+        HCSPMM.forward(torch.zeros(100, 8), torch.from_numpy(rp), torch.from_numpy(col), *outs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D", [32, 128, 22])
+def test_extension_forward_and_fused(HCSPMM, oracle_mod, D):
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda:0")
+    rp, col = graphs.planted_dense_graph(1200, seed=5)
+    N = len(rp) - 1
+    rp_d, col_d = torch.from_numpy(rp).to(dev), torch.from_numpy(col).to(dev)
+    outs = HCSPMM.preprocess(col_d, rp_d, N, len(col), (N + 15) // 16)  # column_index FIRST (HC-SpMM_main.py:52)
+    want = oracle_mod.preprocess(rp, col, oracle_mod.RULE_INTENDED)
+    for w, g in zip(want, outs[:4]):
+        assert g.is_cuda and g.dtype == torch.int32 and np.array_equal(w, g.cpu().numpy())
+    assert int(outs[3].sum()) > 0  # some dense-tile windows
+    rng = np.random.default_rng(D)
+    X = rng.standard_normal((N, D)).astype(np.float32)
+    Xd = torch.from_numpy(X).to(dev)
+    ref = oracle_mod.spmm_f32(rp, col, X)
+    for fn in (HCSPMM.forward, HCSPMM.forward_fixed32, HCSPMM.backward, HCSPMM.forward_more):
+        out = fn(Xd, rp_d, col_d, *outs)
+        assert isinstance(out, list) and len(out) == 1
+        assert np.array_equal(out[0].cpu().numpy(), ref)
+    # reference placeholders for row_nzr / col_nzr -> plan-free kernel, same answer
+    ph = torch.zeros(1, dtype=torch.int32, device=dev)
+    assert np.array_equal(HCSPMM.forward(Xd, rp_d, col_d, outs[0], outs[1], outs[2], outs[3], ph, ph)[0].cpu().numpy(), ref)
+    # a cloned plan tensor (unknown pointer) is recognised by its header
+    assert np.array_equal(HCSPMM.forward(Xd, rp_d, col_d, outs[0], outs[1], outs[2], outs[3], outs[4].clone(),
+                                         outs[5])[0].cpu().numpy(), ref)
+    H = 16
+    W = rng.standard_normal((D, H)).astype(np.float32)
+    Wd = torch.from_numpy(W).to(dev)
+    want_out, want_out2 = oracle_mod.spmm_fused_f32(rp, col, X, W)
+    scale = np.abs(want_out2).astype(np.float64) @ np.abs(W).astype(np.float64)
+    out, out2 = HCSPMM.forward_fixed32_fused(Xd, rp_d, col_d, *outs, Wd)
+    assert np.array_equal(out2.cpu().numpy(), want_out2)
+    assert np.all(np.abs(out.cpu().numpy() - want_out) <= 1e-5 * scale + 1e-30)
+    buf = torch.zeros(N, H, device=dev)
+    out, _ = HCSPMM.forward_final_fused(Xd, rp_d, col_d, *outs, Wd.t().contiguous().t(), buf)
+    assert out.data_ptr() == buf.data_ptr()
+    assert np.all(np.abs(buf.cpu().numpy() - want_out) <= 1e-5 * scale + 1e-30)
+
+
+@pytest.mark.gpu
+def test_extension_as_shipped_rule_and_side_stream(HCSPMM, oracle_mod):
+    dev = torch.device("cuda:0")
+    rp, col = graphs.planted_dense_graph(640, seed=6)
+    N = len(rp) - 1
+    rp_d, col_d = torch.from_numpy(rp).to(dev), torch.from_numpy(col).to(dev)
+    HCSPMM.set_rule(2)
+    try:
+        outs = HCSPMM.preprocess(col_d, rp_d, N, len(col), (N + 15) // 16)
+    finally:
+        HCSPMM.set_rule(0)
+    assert int(outs[3].sum()) == 0  # hybrid_all_kernel.cu:262 as shipped: every window sparse
+    X = np.random.default_rng(0).standard_normal((N, 64)).astype(np.float32)
+    Xd = torch.from_numpy(X).to(dev)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):  # launches follow torch's current stream
+        Z = HCSPMM.forward(Xd, rp_d, col_d, *outs)[0]
+    s.synchronize()
+    assert np.array_equal(Z.cpu().numpy(), oracle_mod.spmm_f32(rp, col, X))

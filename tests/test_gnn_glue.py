@@ -1,0 +1,141 @@
+"""Callers either side of the hot path: dataset loader vs the CSRs the reference's
+own dataset.py produced (CPU), and the GCN/GIN autograd glue + driver against dense autograd (GPU)."""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "hc-spmm_amd")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _pkg_imports():
+    for p in (PKG, os.path.join(PKG, "hybrid_kernel")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+@pytest.mark.parametrize("name", ["five_nodes", "rand_40", "rand_333"])
+def test_dataset_loader_matches_reference_csr(tmp_path, name):
+    _pkg_imports()
+    from dataset import HCSPMM_dataset
+    g = np.load(os.path.join(GOLD, "csr_from_text.npz"))
+    path = tmp_path / (name + ".txt")
+    path.write_bytes(bytes(g[name + "_text"]))
+    ds = HCSPMM_dataset(str(path), 16, 4, load_from_txt=True, device="cpu", seed=0)
+    assert ds.num_nodes == int(g[name + "_num_nodes"]) and ds.num_edges == int(g[name + "_num_edges"])
+    assert ds.row_pointers.dtype == torch.int32 and ds.column_index.dtype == torch.int32
+    assert np.array_equal(ds.row_pointers.numpy(), g[name + "_row_pointers"])
+    assert np.array_equal(ds.column_index.numpy(), g[name + "_column_index"])
+    assert ds.x.shape == (ds.num_nodes, 16) and ds.y.dtype == torch.int64 and int(ds.y.min()) == 1
+    deg = np.diff(g[name + "_row_pointers"])
+    assert np.allclose(ds.degrees.numpy(), np.sqrt(np.where(deg > 0, deg, 1)))
+    # npz branch (dataset.py:69-79): same CSR from the same edges
+    text = bytes(g[name + "_text"]).decode()
+    pairs = np.array([[int(v) for v in ln.split(",")] for ln in text.splitlines()])
+    npz = tmp_path / (name + ".npz")
+    np.savez(npz, src_li=pairs[:, 1] - 1, dst_li=pairs[:, 0] - 1, num_nodes=ds.num_nodes)
+    ds2 = HCSPMM_dataset(str(npz), 8, 4, load_from_txt=False, device="cpu")
+    assert np.array_equal(ds2.column_index.numpy(), ds.column_index.numpy())
+
+
+def test_example_dataset_is_in_reference_format():
+    _pkg_imports()
+    from dataset import HCSPMM_dataset
+    path = os.path.join(PKG, "Dataset", "example.txt")
+    lines = open(path).read().split()
+    second = [int(ln.split(",")[1]) for ln in lines]
+    assert second == sorted(second)  # LOI.cpp:493-499 needs the 2nd field ascending
+    ds = HCSPMM_dataset(path, 16, 22, device="cpu")
+    assert ds.num_nodes == 600 and ds.column_index.numel() == ds.num_edges  # duplicate-free
+
+
+def _dense_adj(rp, col, dev):
+    N = len(rp) - 1
+    A = torch.zeros(N, N, device=dev)
+    rows = np.repeat(np.arange(N), np.diff(rp))
+    A[torch.from_numpy(rows).to(dev), torch.from_numpy(col.astype(np.int64)).to(dev)] = 1.0
+    return A
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family", ["gcn", "gin"])
+@pytest.mark.parametrize("fixed", [1, 0, 2])
+def test_layer_forward_backward_vs_dense_autograd(family, fixed):
+    """Every layer class of GNN_model.py against plain dense autograd on a small SYMMETRIC graph
+    (the backward pass aggregates with A, not A^T, like the reference)."""
+    _pkg_imports()
+    import HCSPMM
+    from GNN_model import GCNConv, GINConv
+    from hcspmm import graphs
+    dev = torch.device("cuda:0")
+    rp, col = graphs.powerlaw_graph(400, 3000, seed=12)  # symmetric by construction
+    N = len(rp) - 1
+    rp_d, col_d = torch.from_numpy(rp).to(dev), torch.from_numpy(col).to(dev)
+    graph = (rp_d, col_d, *HCSPMM.preprocess(col_d, rp_d, N, len(col), (N + 15) // 16))
+    din, dout = (32, 32) if fixed != 2 else (32, 22)
+    torch.manual_seed(0)
+    conv = (GCNConv if family == "gcn" else GINConv)(din, dout, fixed).to(dev)
+    X = torch.randn(N, din, device=dev, requires_grad=True)
+    R = torch.randn(N, dout, device=dev)
+    out_buf = torch.zeros(N, din, device=dev)  # HC-SpMM_main.py:45: num_nodes x hidden
+    Y = conv(X, *graph, out_buf)
+    (Y * R).sum().backward()
+    gX, gW = X.grad.clone(), conv.weights.grad.clone()
+
+    A = _dense_adj(rp, col, dev)
+    Xr = X.detach().clone().requires_grad_(True)
+    Wr = conv.weights.detach().clone().requires_grad_(True)
+    Yr = A @ (Xr @ Wr) if family == "gcn" else (A @ Xr) @ Wr
+    (Yr * R).sum().backward()
+
+    def close(a, b):
+        return (a - b).abs().max().item() <= 2e-4 * b.abs().max().item() + 1e-6
+    assert close(Y.detach(), Yr.detach())
+    assert close(gX, Xr.grad) and close(gW, Wr.grad)
+
+
+@pytest.mark.gpu
+def test_sag_profile_and_known_answer_tensor(capsys):
+    _pkg_imports()
+    import HCSPMM
+    from GNN_model import SAG, gen_test_tensor
+    from hcspmm import graphs
+    dev = torch.device("cuda:0")
+    rp, col = graphs.powerlaw_graph(10000, 50000, seed=1)  # BASELINE config 2
+    N = len(rp) - 1
+    rp_d, col_d = torch.from_numpy(rp).to(dev), torch.from_numpy(col).to(dev)
+    sag = SAG(rp_d, col_d, *HCSPMM.preprocess(col_d, rp_d, N, len(col), (N + 15) // 16))
+    X = gen_test_tensor(torch.empty(N, 32, device=dev))
+    Z = sag(X)
+    want = np.array([col[rp[i]:rp[i + 1]].sum() for i in range(N)], np.float32)
+    assert np.array_equal(Z[:, 0].cpu().numpy(), want) and torch.equal(Z[:, 0], Z[:, 31])
+    ms = sag.profile(torch.randn(N, 32, device=dev), num_rounds=20)
+    assert ms > 0 and "=> SAG profiling avg (ms):" in capsys.readouterr().out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["gcn", "gin"])
+def test_driver_end_to_end_on_example_dataset(model, capsys, monkeypatch):
+    """BASELINE config 1 plumbing: `example` dataset, 2-layer net, dim 16 -- the driver runs preprocess,
+    forward, backward and the optimizer through every layer type."""
+    _pkg_imports()
+    monkeypatch.chdir(PKG)
+    spec = importlib.util.spec_from_file_location("hc_spmm_main", os.path.join(PKG, "HC-SpMM_main.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    torch.manual_seed(0)
+    net = mod.main(["--dataset", "example", "--dim", "16", "--num_layers", "2", "--hidden", "32", "--classes", "22",
+                    "--epochs", "30", "--model", model])
+    out = capsys.readouterr().out
+    assert "Prep. (ms):" in out and "Train (ms/epoch):" in out
+    for name, prm in net.named_parameters():  # the backward pass reached every layer's operator
+        assert prm.grad is not None and torch.isfinite(prm.grad).all(), name
+    net.eval()
+    with torch.no_grad():
+        logp = net()
+    assert logp.shape == (600, 22) and torch.isfinite(logp).all()

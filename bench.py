@@ -35,6 +35,7 @@ WORKLOADS = {
     # name: (nodes per rank, stored entries per rank, default dim, description)
     "reddit": (233000, 11600000, 128, "synthetic power-law, Reddit-scale (BASELINE config 3)"),
     "cora": (10000, 50000, 32, "synthetic power-law, Cora-scale (BASELINE config 2)"),
+    "alldense": (1000000, 0, 128, "every window planted (16 rows sharing 20 columns): dense-tile path only, MFMA-utilisation probe"),
     "dense": (2000000, 0, 128, "planted 16-row groups sharing <=24 columns, dense-tile heavy (BASELINE config 5 shape, per-GPU share)"),
 }
 
@@ -43,9 +44,9 @@ def make_local_block(workload, n_local, e_local, world, rank, seed=3):
     """Row block of `rank`: n_local rows, columns are global ids in [0, world*n_local)."""
     from hcspmm import graphs
     if world == 1:
-        if workload == "dense":
-            return graphs.planted_dense_graph_fast(n_local, seed=seed, dense_fraction=0.7, k_cols=20, fill=0.45,
-                                                   sparse_degree=16)
+        if workload in ("dense", "alldense"):
+            return graphs.planted_dense_graph_fast(n_local, seed=seed, dense_fraction=0.7 if workload == "dense" else 1.0,
+                                                   k_cols=20, fill=0.45, sparse_degree=16)
         return graphs.powerlaw_graph(n_local, e_local, seed=seed)
     # rows follow a local power law, columns a global one (cheap to generate per rank, no exchange)
     rng = np.random.default_rng(seed + 1000 * rank)

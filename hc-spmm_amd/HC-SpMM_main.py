@@ -106,7 +106,7 @@ def main(argv=None):
         loss = train()
     torch.cuda.synchronize()
     print("Train (ms/epoch):\t{:.3f}\tfinal loss {:.4f}".format((time.perf_counter() - t0) * 1e3 / max(args.epochs, 1),
-                                                                 float(loss) if loss is not None else float("nan")))
+                                                                 float(loss.detach()) if loss is not None else float("nan")))
     return model
 
 

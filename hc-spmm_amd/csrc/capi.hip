@@ -42,6 +42,35 @@ extern "C" const char* hcspmm_strerror(int code) {
   }
 }
 
+// Wide-task threshold.  A lane group sums a task with U = 8 loads in flight, so a task of T entries
+// is a chain of T/8 dependent memory round trips; the whole launch is about
+// nnz_sparse / (8 * R * resident waves) such rounds deep.  The threshold is the largest power of two
+// in [16, 256] not exceeding a quarter of that depth times 8: small (latency-bound) launches hand
+// every row longer than 16 entries to a whole wave, large (throughput-bound) ones keep rows up to
+// 256 entries on one lane group, in CSR order.
+static int wide_choice(const hcspmm_plan_header* h, int D, int* n_wide, int* latency_bound = nullptr) {
+  const int vec = (D % 4 == 0) ? 4 : (D % 2 == 0) ? 2 : 1;
+  int L = 4;
+  while (L < (D + vec - 1) / vec && L < 64) L <<= 1;
+  const int R = 64 / L;
+  *n_wide = 0;
+  if (latency_bound) *latency_bound = (double)h->nnz_sparse < 32.0 * 4.0 * 256.0 * 16.0;
+  if (R == 1) return INT32_MAX;
+  const double kResidentWaves = 256.0 * 16.0;
+  const double t = 0.25 * (double)h->nnz_sparse / ((double)R * kResidentWaves);
+  if (latency_bound) *latency_bound = t < 32.0;
+  int b = 0;
+  while (b < 4 && (double)(16 << (b + 1)) <= t) ++b;
+  *n_wide = h->n_len_gt[b];
+  return *n_wide > 0 ? (16 << b) : INT32_MAX;
+}
+
+extern "C" int32_t hcspmm_wide_threshold(const hcspmm_plan_header* h, int D) {
+  if (!h || D <= 0) return INT32_MAX;
+  int n_wide = 0;
+  return wide_choice(h, D, &n_wide);
+}
+
 extern "C" int hcspmm_abi_version(void) { return HCSPMM_ABI_VERSION; }
 extern "C" int hcspmm_last_hip_error(void) { return g_last_hip_error; }
 
@@ -73,6 +102,8 @@ extern "C" int hcspmm_forward(const float* X, float* Z, const int32_t* rowptr, c
     a.n_dense = ph->n_dense;
     a.off_fixups = ph->off_fixups;
     a.n_split_rows = ph->n_split_rows;
+    wide_choice(ph, D, &a.n_wide, &a.latency_bound);
+    a.wide_wgs = 0;
     a.N = (int)N;
     a.D = D;
     a.sparse_wgs = 0;

@@ -146,12 +146,17 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
       }
     }
   }
+  int32_t len_gt[5] = {0, 0, 0, 0, 0};
   {
     const int32_t maxlen = rp.split_threshold;
     std::vector<int64_t> start((size_t)maxlen + 2, 0);
     for (const Task& t : tasks) start[(size_t)(maxlen - t.len) + 1]++;  // bucket 0 = longest
     for (size_t i = 1; i < start.size(); ++i) start[i] += start[i - 1];
     int32_t* out = plan + L.off_tasks;
+    for (int b = 0; b < 5; ++b) {  // prefix sizes: tasks longer than 16 << b
+      const int32_t thr = 16 << b;
+      len_gt[b] = thr >= maxlen ? 0 : (int32_t)start[(size_t)(maxlen - thr)];  // buckets [0, maxlen-thr) hold len > thr
+    }
     for (const Task& t : tasks) {
       const int64_t p = start[(size_t)(maxlen - t.len)]++;
       out[4 * p + 0] = t.row;
@@ -212,6 +217,7 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
   h.nnz_dense = (int32_t)L.nnz_dense;
   h.uniq_dense = (int32_t)uniq_total;
   h.max_dense_k = L.max_dense_k;
+  for (int b = 0; b < 5; ++b) h.n_len_gt[b] = len_gt[b];
   static_assert(sizeof(hcspmm_plan_header) == HCSPMM_PLAN_HEADER_WORDS * 4, "header size");
   std::memcpy(plan, &h, sizeof(h));
   return HCSPMM_OK;

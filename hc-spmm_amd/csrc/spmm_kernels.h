@@ -17,7 +17,9 @@ struct PlanArgs {
   int off_dense_index, off_dense_pack, n_dense;
   int off_fixups, n_split_rows;
   int N, D;
-  int sparse_wgs, n_panels;  // filled by the launcher
+  int n_wide;                          // the n_wide longest tasks are summed by whole waves
+  int latency_bound;                   // small launch: use the deep-MLP / low-occupancy build
+  int wide_wgs, sparse_wgs, n_panels;  // filled by the launcher
 };
 
 // Arguments of the plan-free launch: the reference's seven graph tensors as they are.

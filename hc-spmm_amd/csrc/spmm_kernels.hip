@@ -46,6 +46,15 @@ __device__ __forceinline__ void vset(float& v, int, float x) { v = x; }
 
 constexpr int kWaves = 4;            // waves per workgroup (256 threads)
 constexpr int kThreads = kWaves * 64;
+#ifndef HCSPMM_SPARSE_U
+#define HCSPMM_SPARSE_U 4  // row loads in flight per lane on the sparse-row path
+#endif
+#ifndef HCSPMM_DENSE_B
+#define HCSPMM_DENSE_B 4   // k-steps (row loads in flight per lane) per batch on the dense-tile path
+#endif
+#ifndef HCSPMM_MIN_WAVES_PER_SIMD
+#define HCSPMM_MIN_WAVES_PER_SIMD 8  // 64 registers per lane: 8 waves per SIMD (measured best: profiles/r01/ab_u_b_mw.log)
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Sparse-row task body: the L lanes [lane & ~(L-1), +L) own one task (row or row segment)
@@ -53,25 +62,36 @@ constexpr int kThreads = kWaves * 64;
 // flow is wave-uniform (loop bounds come from the wave-wide maximum n); shorter tasks are
 // predicated off by idx = -1, and adding the resulting 0.0f is exact.
 // ------------------------------------------------------------------------------------------
-template <int L, int VEC>
+template <int L, int VEC, bool WIDE, int UMAX = HCSPMM_SPARSE_U>
 __device__ __forceinline__ void sparse_task(const float* __restrict__ X, float* __restrict__ dst,
                                             const int* __restrict__ col, int e0, int n, int D, int lane) {
   typedef typename VecT<VEC>::type vec_t;
-  constexpr int U = (L < 8) ? L : 8;  // loads in flight per lane
+  constexpr int U = (L < UMAX) ? L : UMAX;  // loads in flight per lane
+  // WIDE: the whole wave owns ONE task (e0, n wave-uniform); per 64-entry super-chunk lane i holds
+  // entry base+i, so lane group g sums entries [base + g*L, base + (g+1)*L) and the 64/L group sums
+  // are combined by a fixed xor-shuffle tree at the end.  Otherwise each lane group owns its own task.
+  constexpr int STRIDE = WIDE ? 64 : L;
   const int s = lane & (L - 1);
+  const int pos = WIDE ? lane : s;
   const int gbase = lane & ~(L - 1);
   int nmax = n;
+  if (!WIDE) {
 #pragma unroll
-  for (int off = L; off < 64; off <<= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
+    for (int off = L; off < 64; off <<= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
+  }
   nmax = __builtin_amdgcn_readfirstlane(nmax);
 
   for (int pbase = 0; pbase < D; pbase += L * VEC) {
     const int c = pbase + s * VEC;
     const bool cok = c < D;
     vec_t acc = vzero<VEC>();
-    for (int base = 0; base < nmax; base += L) {
-      const int myidx = (base + s < n) ? col[e0 + base + s] : -1;
-      const int cnt = min(L, nmax - base);
+    // the next chunk's indices are requested before the current chunk's rows, so a chunk costs one
+    // memory round trip instead of two
+    int next = (pos < n) ? col[e0 + pos] : -1;
+    for (int base = 0; base < nmax; base += STRIDE) {
+      const int myidx = next;
+      next = (base + STRIDE + pos < n) ? col[e0 + base + STRIDE + pos] : -1;
+      const int cnt = min(L, nmax - base);  // longest lane group's share of this chunk
       for (int j = 0; j < cnt; j += U) {
         vec_t v[U];
 #pragma unroll
@@ -84,7 +104,16 @@ __device__ __forceinline__ void sparse_task(const float* __restrict__ X, float* 
         for (int u = 0; u < U; ++u) acc += v[u];
       }
     }
-    if (cok && dst != nullptr) *reinterpret_cast<vec_t*>(dst + c) = acc;
+    if (WIDE) {
+#pragma unroll
+      for (int off = L; off < 64; off <<= 1) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) vset(acc, q, vget(acc, q) + __shfl_xor(vget(acc, q), off, 64));
+      }
+      if (cok && dst != nullptr && lane < L) *reinterpret_cast<vec_t*>(dst + c) = acc;
+    } else {
+      if (cok && dst != nullptr) *reinterpret_cast<vec_t*>(dst + c) = acc;
+    }
   }
 }
 
@@ -110,11 +139,12 @@ __device__ __forceinline__ void dense_unit(const float* __restrict__ X, float* _
   for (int kb = 0; kb < K4; kb += 16) {
     const int myU = (kb * 4 + lane < K4 * 4) ? U[kb * 4 + lane] : -1;
     const int steps = min(16, K4 - kb);
-    for (int t0 = 0; t0 < steps; t0 += 4) {
-      vec_t x[4];
-      float a[4];
+    constexpr int B = HCSPMM_DENSE_B;
+    for (int t0 = 0; t0 < steps; t0 += B) {
+      vec_t x[B];
+      float a[B];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < B; ++u) {
         const int t = t0 + u;  // may run past `steps`: U pad (-1) and zero masks make it a no-op
         const int idx = (t < steps) ? __shfl(myU, (4 * t + kq) & 63, 64) : -1;
         const unsigned long long m = (t < steps) ? masks[kb + t] : 0ull;
@@ -123,7 +153,7 @@ __device__ __forceinline__ void dense_unit(const float* __restrict__ X, float* _
         if (cok && idx >= 0) x[u] = *reinterpret_cast<const vec_t*>(X + (size_t)idx * (size_t)D + c);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < B; ++u) {
 #pragma unroll
         for (int q = 0; q < VEC; ++q)
           acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], vget(x[u], q), acc[q], 0, 0, 0);
@@ -146,16 +176,26 @@ __device__ __forceinline__ void dense_unit(const float* __restrict__ X, float* _
 
 // ------------------------------------------------------------------------------------------
 // Planned hybrid kernel: ONE launch covers both sub-paths (as the reference's single launch
-// does, K.cu:960/1039) -- workgroups [0, sparse_wgs) run sparse tasks, the rest dense units.
+// does, K.cu:960/1039) -- workgroups [0, wide_wgs) run wide sparse tasks, [wide_wgs, sparse_wgs) ordinary ones, the rest dense units.
 // ------------------------------------------------------------------------------------------
-template <int L, int VEC>
-__global__ __launch_bounds__(kThreads) void hybrid_plan_kernel(PlanArgs a) {
+// Two builds of the same kernel: <U = 4, 8 waves/SIMD> for throughput-bound launches (64 registers,
+// full occupancy) and <U = 8, 4 waves/SIMD> for latency-bound ones (few waves, deeper per-wave MLP).
+template <int L, int VEC, int UNROLL, int MINW>
+__global__ __launch_bounds__(kThreads, MINW) void hybrid_plan_kernel(PlanArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if ((int)blockIdx.x < a.sparse_wgs) {
+  if ((int)blockIdx.x < a.wide_wgs) {
+    // wide tasks: the a.n_wide longest tasks, one per wave
+    const int tid = (int)blockIdx.x * kWaves + wave;
+    if (tid >= a.n_wide) return;
+    const int4 t = reinterpret_cast<const int4*>(a.plan + a.off_tasks)[tid];
+    float* dst = (t.w < 0) ? a.Z + (size_t)t.x * (size_t)a.D : a.partial + (size_t)t.w * (size_t)a.D;
+    sparse_task<L, VEC, true, UNROLL>(a.X, dst, a.col, __builtin_amdgcn_readfirstlane(t.y),
+                              __builtin_amdgcn_readfirstlane(t.z), a.D, lane);
+  } else if ((int)blockIdx.x < a.sparse_wgs) {
     constexpr int R = 64 / L;
     const int g = lane / L;
-    const int tid = ((int)blockIdx.x * kWaves + wave) * R + g;
+    const int tid = a.n_wide + (((int)blockIdx.x - a.wide_wgs) * kWaves + wave) * R + g;
     int e0 = 0, n = 0;
     float* dst = nullptr;
     if (tid < a.n_tasks) {
@@ -164,7 +204,7 @@ __global__ __launch_bounds__(kThreads) void hybrid_plan_kernel(PlanArgs a) {
       n = t.z;
       dst = (t.w < 0) ? a.Z + (size_t)t.x * (size_t)a.D : a.partial + (size_t)t.w * (size_t)a.D;
     }
-    sparse_task<L, VEC>(a.X, dst, a.col, e0, n, a.D, lane);
+    sparse_task<L, VEC, false, UNROLL>(a.X, dst, a.col, e0, n, a.D, lane);
   } else {
     const int unit = ((int)blockIdx.x - a.sparse_wgs) * kWaves + wave;
     if (unit >= a.n_dense * a.n_panels) return;
@@ -187,8 +227,17 @@ __global__ __launch_bounds__(kThreads) void fixup_kernel(PlanArgs a) {
   const int4 f = reinterpret_cast<const int4*>(a.plan + a.off_fixups)[fi];
   const int row = f.x, s0 = f.y, ns = f.z;
   for (int c = lane * VEC; c < a.D; c += 64 * VEC) {
-    vec_t acc = *reinterpret_cast<const vec_t*>(a.partial + (size_t)s0 * (size_t)a.D + c);
-    for (int s = 1; s < ns; ++s) acc += *reinterpret_cast<const vec_t*>(a.partial + (size_t)(s0 + s) * (size_t)a.D + c);
+    const float* p = a.partial + (size_t)s0 * (size_t)a.D + c;
+    vec_t acc = *reinterpret_cast<const vec_t*>(p);
+    int s = 1;
+    for (; s + 4 <= ns; s += 4) {  // four independent loads in flight, added in segment order
+      vec_t v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const vec_t*>(p + (size_t)(s + u) * (size_t)a.D);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc += v[u];
+    }
+    for (; s < ns; ++s) acc += *reinterpret_cast<const vec_t*>(p + (size_t)s * (size_t)a.D);
     *reinterpret_cast<vec_t*>(a.Z + (size_t)row * (size_t)a.D + c) = acc;
   }
 }
@@ -224,7 +273,7 @@ __global__ __launch_bounds__(kThreads) void hybrid_window_kernel(WindowArgs a) {
         n = a.rowptr[r + 1] - e0;
         dst = a.Z + (size_t)r * (size_t)a.D;
       }
-      sparse_task<L, VEC>(a.X, dst, a.col, e0, n, a.D, lane);
+      sparse_task<L, VEC, false>(a.X, dst, a.col, e0, n, a.D, lane);
     }
     return;
   }
@@ -300,13 +349,21 @@ template <int L, int VEC>
 static hipError_t launch_plan_LV(const PlanArgs& a, hipStream_t stream) {
   constexpr int R = 64 / L;
   PlanArgs b = a;
-  b.sparse_wgs = (a.n_tasks + kWaves * R - 1) / (kWaves * R);
+  b.n_wide = (R > 1) ? a.n_wide : 0;  // with one lane group per wave a wide task is an ordinary one
+  b.wide_wgs = (b.n_wide + kWaves - 1) / kWaves;
+  b.sparse_wgs = b.wide_wgs + (a.n_tasks - b.n_wide + kWaves * R - 1) / (kWaves * R);
   b.n_panels = (a.D + 16 * VEC - 1) / (16 * VEC);
   const long long dense_units = (long long)a.n_dense * b.n_panels;
   const long long dense_wgs = (dense_units + kWaves - 1) / kWaves;
   const long long grid = (long long)b.sparse_wgs + dense_wgs;
   if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
-  if (grid > 0) hipLaunchKernelGGL((hybrid_plan_kernel<L, VEC>), dim3((unsigned)grid), dim3(kThreads), 0, stream, b);
+  if (grid > 0) {
+    if (a.latency_bound)
+      hipLaunchKernelGGL((hybrid_plan_kernel<L, VEC, 8, 4>), dim3((unsigned)grid), dim3(kThreads), 0, stream, b);
+    else
+      hipLaunchKernelGGL((hybrid_plan_kernel<L, VEC, HCSPMM_SPARSE_U, HCSPMM_MIN_WAVES_PER_SIMD>), dim3((unsigned)grid),
+                         dim3(kThreads), 0, stream, b);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (a.n_split_rows > 0) {

@@ -21,7 +21,7 @@ __all__ = [
     "forward_fixed64_fused", "forward_final_fused", "forward_final_fused_64", "forward_GIN_final_fused", "backward",
     "backward_fixed32", "backward_fixed32_fused", "backward_final_fused", "backward_fixed64",
     "backward_fixed64_fused", "backward_final_fused_64", "backward_GIN_final_fused", "loi_reorder",
-    "apply_permutation", "plan_header", "forward_rect", "set_default_rule", "RULE_INTENDED", "RULE_INTENDED_GUARD",
+    "apply_permutation", "plan_header", "forward_rect", "wide_threshold", "set_default_rule", "RULE_INTENDED", "RULE_INTENDED_GUARD",
     "RULE_AS_SHIPPED",
 ]
 
@@ -67,6 +67,15 @@ def plan_header(row_nzr, num_nodes=None, num_edges=None):
         return None
     _register(row_nzr, h)
     return h
+
+
+def wide_threshold(row_nzr, embedding_dim):
+    """Rows of the sparse path with more entries than this are summed by a whole wave (shuffle-tree
+    combine) instead of one lane group in CSR order; see hcspmm_wide_threshold in include/hcspmm.h."""
+    h = plan_header(row_nzr)
+    if h is None:
+        return 2 ** 31 - 1
+    return int(lib().hcspmm_wide_threshold(ctypes.byref(h), int(embedding_dim)))
 
 
 def _ptr(t):

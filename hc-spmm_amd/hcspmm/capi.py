@@ -19,7 +19,8 @@ class Header(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "magic", "version", "total_words", "num_nodes", "num_edges", "num_windows", "split_threshold", "segment_len",
         "n_tasks", "n_dense", "n_split_rows", "n_partials", "off_tasks", "off_dense_index", "off_dense_pack",
-        "off_fixups", "nnz_sparse", "nnz_dense", "uniq_dense", "max_dense_k")] + [("reserved", ctypes.c_int32 * 12)]
+        "off_fixups", "nnz_sparse", "nnz_dense", "uniq_dense", "max_dense_k")] + [("n_len_gt", ctypes.c_int32 * 5),
+                                                                                  ("reserved", ctypes.c_int32 * 7)]
 
 
 class PlanParams(ctypes.Structure):
@@ -39,6 +40,7 @@ SYMBOLS = {
     "hcspmm_plan_build": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _pp, _vp, _i64]),
     "hcspmm_plan_check": (_int, [_hp, _i64, _i64]),
     "hcspmm_workspace_bytes": (_sz, [_hp, _int]),
+    "hcspmm_wide_threshold": (ctypes.c_int32, [_hp, _int]),
     "hcspmm_forward": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _hp, _i64, _i64, _int, _vp, _sz, _vp]),
     "hcspmm_forward_fused": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _hp,
                                     _i64, _i64, _int, _vp, _sz, _vp]),

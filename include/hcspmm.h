@@ -73,7 +73,7 @@ int hcspmm_preprocess_host(const int32_t* row_pointers_h, const int32_t* column_
  * read-back).
  * ---------------------------------------------------------------------------------------- */
 #define HCSPMM_PLAN_MAGIC 0x48435350 /* "HCSP" */
-#define HCSPMM_PLAN_VERSION 2
+#define HCSPMM_PLAN_VERSION 3
 #define HCSPMM_PLAN_HEADER_WORDS 32
 
 typedef struct hcspmm_plan_header {
@@ -97,7 +97,10 @@ typedef struct hcspmm_plan_header {
   int32_t nnz_dense;        /* entries handled by the dense-tile path */
   int32_t uniq_dense;       /* sum of unique columns over dense windows (gathered X rows) */
   int32_t max_dense_k;      /* largest padded K (8*blockPartition) among dense windows */
-  int32_t reserved[12];
+  int32_t n_len_gt[5];      /* tasks longer than 16, 32, 64, 128, 256 entries (tasks are length-sorted,
+                               so these are prefix sizes: the launch can hand the n longest tasks to
+                               whole waves -- "wide" tasks -- at any of these thresholds) */
+  int32_t reserved[7];
 } hcspmm_plan_header;
 
 /* Tunables for the plan; zero-initialise for defaults. */
@@ -122,6 +125,15 @@ int hcspmm_plan_check(const hcspmm_plan_header* header_h, int64_t num_nodes, int
 
 /* Bytes of device workspace hcspmm_forward* needs for this plan and embedding_dim (may be 0). */
 size_t hcspmm_workspace_bytes(const hcspmm_plan_header* header_h, int embedding_dim);
+
+/* Wide-task threshold hcspmm_forward will use for this plan and embedding_dim: sparse-path rows
+ * (or row segments) with more entries than this are summed by a whole wave -- its 64/L lane groups
+ * take alternate chunks and are combined by a fixed shuffle tree (deterministic, but not the
+ * sequential CSR order); rows at or below it are summed strictly in CSR order by one lane group,
+ * bit-identical to the reference's sparse-row loop (K.cu:1377-1380).  Small graphs get a small
+ * threshold (latency-bound: the longest row's dependent-load chain is the kernel time), large
+ * graphs a large one (throughput-bound).  Returns INT32_MAX when no task is wide. */
+int32_t hcspmm_wide_threshold(const hcspmm_plan_header* header_h, int embedding_dim);
 
 /* ------------------------------------------------------------------------------------------
  * forward: Z = A * X.  Replaces the launchers spmm_forward_plus K.cu:410-455,

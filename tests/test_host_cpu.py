@@ -164,6 +164,7 @@ def test_plan_covers_every_entry_exactly_once(name, gen):
         cover[lo:hi] += 1
         rows_written[w * 16:min(w * 16 + 16, N)] += 1
     assert np.all(cover == 1) and np.all(rows_written == 1)
+    assert list(h.n_len_gt) == [int((lens > (16 << b)).sum()) for b in range(5)]
     assert h.nnz_sparse + h.nnz_dense == E
 
 

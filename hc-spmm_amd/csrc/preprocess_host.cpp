@@ -38,8 +38,9 @@ void process_windows(const int32_t* rowptr, const int32_t* col, int64_t N, int64
   for (int64_t w = w_begin; w < w_end; ++w) {
     const int64_t r0 = w * HCSPMM_BLK_H, r1 = std::min<int64_t>(r0 + HCSPMM_BLK_H, N);
     const int64_t lo = rowptr[r0], hi = rowptr[r1];
-    for (int64_t r = r0; r < r1; ++r)
-      for (int64_t e = rowptr[r]; e < rowptr[r + 1]; ++e) edgeToRow[e] = (int32_t)r;
+    if (edgeToRow)  // optional: callers with the graph in HBM expand row ids there instead
+      for (int64_t r = r0; r < r1; ++r)
+        for (int64_t e = rowptr[r]; e < rowptr[r + 1]; ++e) edgeToRow[e] = (int32_t)r;
     if (hi == lo) {  // reference returns early and leaves garbage (K.cu:252-253); defined as 0/0
       blockPartition[w] = 0;
       hybrid_type[w] = 0;
@@ -76,7 +77,7 @@ extern "C" int hcspmm_preprocess_host(const int32_t* rowptr, const int32_t* col,
                                       int num_threads, int32_t* blockPartition, int32_t* edgeToColumn,
                                       int32_t* edgeToRow, int32_t* hybrid_type) {
   if (N < 0 || E < 0 || !rowptr) return HCSPMM_EINVAL;
-  if (E > 0 && (!col || !edgeToColumn || !edgeToRow)) return HCSPMM_EINVAL;
+  if (E > 0 && (!col || !edgeToColumn)) return HCSPMM_EINVAL;  // edgeToRow may be NULL (skipped)
   if (rule < HCSPMM_RULE_INTENDED || rule > HCSPMM_RULE_AS_SHIPPED) return HCSPMM_EINVAL;
   if (N > INT32_MAX - 16 || E > INT32_MAX) return HCSPMM_ERANGE;
   const int64_t W = (N + HCSPMM_BLK_H - 1) / HCSPMM_BLK_H;
@@ -85,7 +86,7 @@ extern "C" int hcspmm_preprocess_host(const int32_t* rowptr, const int32_t* col,
   for (int64_t r = 0; r < N; ++r)
     if (rowptr[r + 1] < rowptr[r]) return HCSPMM_EINVAL;
 
-  int T = num_threads > 0 ? num_threads : (int)std::thread::hardware_concurrency();
+  int T = num_threads > 0 ? num_threads : std::min(64, (int)std::thread::hardware_concurrency());
   if (T < 1) T = 1;
   if (W < 4 * T || E < (1 << 16)) T = 1;
   if (T == 1) {

@@ -6,6 +6,7 @@
 // v_mfma_f32_16x16x4_f32, any D and H, arbitrary element strides for W (so the transposed view
 // the reference's backward passes, GNN_model.py:98,120, is consumed without a copy).
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 
 #include "spmm_kernels.h"
 
@@ -60,9 +61,98 @@ __global__ __launch_bounds__(kUpdWaves * 64) void dense_update_kernel(const floa
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Streaming variant for the shapes GNN layers use (H = 16*T, T <= 4; D % 16 == 0; 16-byte aligned
+// rows): the kernel is bound by reading agg once, so
+//  * W is staged in LDS once per workgroup and the workgroup strides over many 64-row tiles;
+//  * a lane loads agg with 16-byte accesses: lane (i = l & 15, kq = l >> 4) takes
+//    agg[row i][16*kk + 4*kq .. +4), and the q-th of its four floats feeds k-step q -- the k order
+//    inside a 16-chunk is a fixed permutation, applied to the W rows as well;
+//  * tile t of a k-step multiplies by W columns T*j + t, so the T results of a lane are T
+//    consecutive output columns and leave as one vector store.
+// The accumulation order per output element is a fixed permutation of k (deterministic).
+// ------------------------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(kUpdWaves * 64) void dense_update_stream_kernel(const float* __restrict__ in,
+                                                                             const float* __restrict__ W,
+                                                                             long long ldr, long long ldc,
+                                                                             float* __restrict__ out, int N, int D) {
+  extern __shared__ __attribute__((aligned(16))) float s_w[];  // [D][HS], HS = 16*T + 4 (row stride = 4 mod 8 words)
+  constexpr int H = 16 * T;
+  constexpr int HS = H + 4;
+  for (int i = threadIdx.x; i < D * H; i += kUpdWaves * 64) {
+    const int k = i / H, h = i - k * H;
+    s_w[k * HS + h] = W[(long long)k * ldr + (long long)h * ldc];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int tiles = (N + 15) / 16;
+  for (int tile = (int)blockIdx.x * kUpdWaves + wave; tile < tiles; tile += (int)gridDim.x * kUpdWaves) {
+    const int r0 = tile * 16;
+    const int row = r0 + i;
+    const bool rok = row < N;
+    const f32x4* arow = reinterpret_cast<const f32x4*>(in + (size_t)(rok ? row : 0) * (size_t)D) + kq;
+    f32x4 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < D; k0 += 64) {  // four 16-chunks of agg in flight
+      f32x4 a[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (rok && k0 + 16 * u < D) a[u] = arow[(k0 >> 2) + 4 * u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (k0 + 16 * u < D) {
+          const float* wrow = s_w + (k0 + 16 * u + 4 * kq) * HS + T * i;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+              acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][q], wrow[q * HS + t], acc[t], 0, 0, 0);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int orow = r0 + 4 * kq + r;
+      if (orow < N) {
+        float* o = out + (size_t)orow * (size_t)H + T * i;
+#pragma unroll
+        for (int t = 0; t < T; ++t) o[t] = acc[t][r];
+      }
+    }
+  }
+}
+
+template <int T>
+static hipError_t launch_stream(const float* in, const float* W, long long ldr, long long ldc, float* out, int N, int D,
+                                hipStream_t stream) {
+  const size_t lds = (size_t)D * (16 * T + 4) * sizeof(float);
+  const int tiles = (N + 15) / 16;
+  int grid = (tiles + kUpdWaves - 1) / kUpdWaves;
+  if (grid > 1024) grid = 1024;  // W is staged once per workgroup: stride over the row tiles
+  hipLaunchKernelGGL((dense_update_stream_kernel<T>), dim3(grid), dim3(kUpdWaves * 64), lds, stream, in, W, ldr, ldc,
+                     out, N, D);
+  return hipGetLastError();
+}
+
 hipError_t launch_dense_update(const float* in, const float* W, long long ldr, long long ldc, float* out, int N,
                                int D, int H, hipStream_t stream) {
   if (N <= 0 || H <= 0) return hipSuccess;
+  const bool aligned16 = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  if (aligned16 && D % 16 == 0 && H % 16 == 0 && H <= 64 && (size_t)D * (H + 4) * sizeof(float) <= 64 * 1024) {
+    switch (H / 16) {
+      case 1: return launch_stream<1>(in, W, ldr, ldc, out, N, D, stream);
+      case 2: return launch_stream<2>(in, W, ldr, ldc, out, N, D, stream);
+      case 3: return launch_stream<3>(in, W, ldr, ldc, out, N, D, stream);
+      default: return launch_stream<4>(in, W, ldr, ldc, out, N, D, stream);
+    }
+  }
   const int rows_per_wg = 16 * kUpdWaves;
   const int grid = (N + rows_per_wg - 1) / rows_per_wg;
   hipLaunchKernelGGL(dense_update_kernel, dim3(grid), dim3(kUpdWaves * 64), 0, stream, in, W, ldr, ldc, out, N, D, H);

@@ -21,7 +21,7 @@ __all__ = [
     "forward_fixed64_fused", "forward_final_fused", "forward_final_fused_64", "forward_GIN_final_fused", "backward",
     "backward_fixed32", "backward_fixed32_fused", "backward_final_fused", "backward_fixed64",
     "backward_fixed64_fused", "backward_final_fused_64", "backward_GIN_final_fused", "loi_reorder",
-    "apply_permutation", "plan_header", "forward_rect", "wide_threshold", "set_default_rule", "RULE_INTENDED", "RULE_INTENDED_GUARD",
+    "apply_permutation", "plan_header", "forward_rect", "wide_threshold", "build_plan", "set_default_rule", "RULE_INTENDED", "RULE_INTENDED_GUARD",
     "RULE_AS_SHIPPED",
 ]
 
@@ -105,22 +105,49 @@ def preprocess(column_index, row_pointers, num_nodes, num_edges, num_row_windows
     W = (N + 15) // 16
     if int(num_row_windows) != W:
         raise RuntimeError("preprocess: num_row_windows (%d) != ceil(N/16) (%d)" % (num_row_windows, W))
-    bp = torch.zeros(W, dtype=torch.int32)
-    ht = torch.zeros(W, dtype=torch.int32)
-    e2c = torch.zeros(E, dtype=torch.int32)
-    e2r = torch.zeros(E, dtype=torch.int32)
+    bp = torch.empty(W, dtype=torch.int32)
+    ht = torch.empty(W, dtype=torch.int32)
+    e2c = torch.empty(E, dtype=torch.int32)
+    on_gpu = dev.type == "cuda"
+    # edgeToRow is the plain CSR row expansion: made on the device when the graph lives there
+    e2r = None if on_gpu else torch.empty(E, dtype=torch.int32)
     r = _DEFAULT_RULE if rule is None else int(rule)
     check(L.hcspmm_preprocess_host(_ptr(rp_h), _ptr(col_h), N, E, r, 0, _ptr(bp), _ptr(e2c), _ptr(e2r), _ptr(ht)))
     words = ctypes.c_int64(0)
     check(L.hcspmm_plan_words(_ptr(rp_h), N, E, _ptr(bp), _ptr(ht), ctypes.byref(_PLAN_PARAMS), ctypes.byref(words)))
-    plan = torch.zeros(max(int(words.value), Header.WORDS), dtype=torch.int32)
+    plan = torch.empty(max(int(words.value), Header.WORDS), dtype=torch.int32)
     check(L.hcspmm_plan_build(_ptr(rp_h), _ptr(col_h), N, E, _ptr(bp), _ptr(e2c), _ptr(ht),
                               ctypes.byref(_PLAN_PARAMS), _ptr(plan), plan.numel()))
+    if on_gpu:
+        rp_dev = row_pointers.to(device=dev, dtype=torch.int64)
+        e2r = torch.repeat_interleave(torch.arange(N, dtype=torch.int32, device=dev), rp_dev[1:] - rp_dev[:-1],
+                                      output_size=E)
     h = Header.from_buffer_copy(plan[:Header.WORDS].numpy().tobytes())
-    outs = [t.to(dev) for t in (bp, e2c, e2r, ht, plan)]
+    outs = [t.to(dev) for t in (bp, e2c, e2r, ht, plan)]  # .to() is a no-op for the device-made e2r
     _register(outs[4], h)
     col_nzr = torch.zeros(1, dtype=torch.int32, device=dev)
     return [outs[0], outs[1], outs[2], outs[3], outs[4], col_nzr]
+
+
+def build_plan(row_pointers, column_index, blockPartition, edgeToColumn, hybrid_type, device=None,
+               split_threshold=0, segment_len=0):
+    """Launch plan for an arbitrary window classification (e.g. every window forced onto one sub-path,
+    or a classifier of the caller's own): -> plan tensor to pass as `row_nzr`."""
+    L = lib()
+    rp_h, col_h = _i32_host(row_pointers), _i32_host(column_index)
+    bp_h, e2c_h, ht_h = _i32_host(blockPartition), _i32_host(edgeToColumn), _i32_host(hybrid_type)
+    N, E = rp_h.numel() - 1, col_h.numel()
+    params = PlanParams(int(split_threshold), int(segment_len)) if (split_threshold or segment_len) else _PLAN_PARAMS
+    words = ctypes.c_int64(0)
+    check(L.hcspmm_plan_words(_ptr(rp_h), N, E, _ptr(bp_h), _ptr(ht_h), ctypes.byref(params), ctypes.byref(words)))
+    plan = torch.empty(max(int(words.value), Header.WORDS), dtype=torch.int32)
+    check(L.hcspmm_plan_build(_ptr(rp_h), _ptr(col_h), N, E, _ptr(bp_h), _ptr(e2c_h), _ptr(ht_h), ctypes.byref(params),
+                              _ptr(plan), plan.numel()))
+    h = Header.from_buffer_copy(plan[:Header.WORDS].numpy().tobytes())
+    dev = torch.device(device) if device is not None else row_pointers.device
+    plan_d = plan.to(dev)
+    _register(plan_d, h)
+    return plan_d
 
 
 def _check_input(t, name):

@@ -166,14 +166,23 @@ std::vector<torch::Tensor> preprocess(torch::Tensor edgeList_tensor, torch::Tens
   TORCH_CHECK(num_nodes == N, "preprocess: num_nodes (", num_nodes, ") != row_pointers.size(0)-1 (", N, ")");
   TORCH_CHECK(block_num == W, "preprocess: num_row_windows (", block_num, ") != ceil(N/16) (", W, ")");
   auto opts = torch::TensorOptions().dtype(torch::kInt);
-  auto bp = torch::zeros({W}, opts), ht = torch::zeros({W}, opts);
-  auto e2c = torch::zeros({E}, opts), e2r = torch::zeros({E}, opts);
-  check_rc(hcspmm_preprocess_host(rp.data_ptr<int>(), iptr(col), N, E, g_rule, 0, mptr(bp), mptr(e2c), mptr(e2r),
-                                  mptr(ht)),
+  auto bp = torch::empty({W}, opts), ht = torch::empty({W}, opts), e2c = torch::empty({E}, opts);
+  // edgeToRow is the plain CSR row expansion (reference fill_edgeToRow, K.cu:314-326): made on the
+  // device when the graph lives there, so 4*E bytes skip the host round trip
+  torch::Tensor e2r;
+  if (dev.is_cuda()) {
+    auto rp64 = nodePointer_tensor.to(dev, torch::kLong);
+    e2r = torch::repeat_interleave(torch::arange(N, torch::TensorOptions().dtype(torch::kInt).device(dev)),
+                                   rp64.slice(0, 1, N + 1) - rp64.slice(0, 0, N), /*dim=*/c10::nullopt, /*output_size=*/E);
+  } else {
+    e2r = torch::empty({E}, opts);
+  }
+  check_rc(hcspmm_preprocess_host(rp.data_ptr<int>(), iptr(col), N, E, g_rule, 0, mptr(bp), mptr(e2c),
+                                  dev.is_cuda() ? nullptr : mptr(e2r), mptr(ht)),
            "preprocess");
   int64_t words = 0;
   check_rc(hcspmm_plan_words(rp.data_ptr<int>(), N, E, iptr(bp), iptr(ht), &g_params, &words), "preprocess(plan size)");
-  auto plan = torch::zeros({std::max<int64_t>(words, HCSPMM_PLAN_HEADER_WORDS)}, opts);
+  auto plan = torch::empty({std::max<int64_t>(words, HCSPMM_PLAN_HEADER_WORDS)}, opts);
   check_rc(hcspmm_plan_build(rp.data_ptr<int>(), iptr(col), N, E, iptr(bp), iptr(e2c), iptr(ht), &g_params,
                              plan.data_ptr<int>(), plan.numel()),
            "preprocess(plan build)");

@@ -55,6 +55,8 @@ int hcspmm_last_hip_error(void);
  *   row_pointers_h[N+1], column_index_h[E] : CSR, columns ascending & unique within a row
  *   blockPartition_h[W], hybrid_type_h[W], edgeToColumn_h[E], edgeToRow_h[E] : outputs, W = ceil(N/16)
  *   num_threads <= 0 : use all host cores.
+ *   edgeToRow_h may be NULL (not produced): it is the plain CSR row expansion, which a caller whose
+ *   graph lives in HBM can generate there without a host round trip.
  * ---------------------------------------------------------------------------------------- */
 int hcspmm_preprocess_host(const int32_t* row_pointers_h, const int32_t* column_index_h, int64_t num_nodes,
                            int64_t num_edges, int rule, int num_threads, int32_t* blockPartition_h,

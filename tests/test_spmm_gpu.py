@@ -38,9 +38,10 @@ class Graph:
         self.rp_d, self.col_d = _t(rp, dev), _t(col, dev)
         outs = hcspmm.preprocess(self.col_d, self.rp_d, self.N, self.E, (self.N + 15) // 16, rule=rule)
         self.bp, self.e2c, self.e2r, self.ht, self.row_nzr, self.col_nzr = outs
-        if force_type is not None:  # force every window onto one sub-path; the plan must be rebuilt for it
+        if force_type is not None:  # force every window onto one sub-path
             self.ht = torch.full_like(self.ht, force_type)
-            plan = False
+            if plan:  # ... and rebuild the plan for that classification
+                self.row_nzr = hcspmm.build_plan(self.rp_d, self.col_d, self.bp, self.e2c, self.ht)
         if not plan:  # the reference's [0] placeholders -> plan-free kernel
             self.row_nzr = torch.zeros(1, dtype=torch.int32, device=dev)
 
@@ -86,7 +87,7 @@ def test_mfma_operand_layout_single_tile(oracle_mod, dev):
     for D in (16, 64, 20):
         X = (np.arange(N)[:, None] * 100 + np.arange(D)[None, :]).astype(np.float32)
         for plan in (True, False):
-            g = Graph(rp, col, dev, plan=plan, force_type=1 if not plan else None)
+            g = Graph(rp, col, dev, plan=plan, force_type=1)
             if plan:
                 assert int(g.ht[0]) == 1  # tiny window -> dense-tile path under the intended rule
             Z = g.forward(_t(X, dev)).cpu().numpy()
@@ -128,6 +129,23 @@ def test_forward_parity_plan_free(oracle_mod, dev, name, gen, split_free, D, mod
     g = Graph(rp, col, dev, plan=False, force_type=force)
     X = np.random.default_rng(1).standard_normal((g.N, D)).astype(np.float32)
     _check(oracle_mod, g, X, g.forward(_t(X, dev)), exact_bits=True)  # no row is ever split here
+
+
+@pytest.mark.parametrize("name,gen,split_free", CASES[:4], ids=[c[0] for c in CASES[:4]])
+@pytest.mark.parametrize("D", [32, 128, 20])
+@pytest.mark.parametrize("force", [0, 1])
+def test_forward_parity_planned_forced_types(oracle_mod, dev, name, gen, split_free, D, force):
+    """Planned kernel with every window forced onto one sub-path.  All-dense exercises dense windows
+    far beyond the classifier's reach: hundreds to thousands of condensed columns (the 64-column
+    chunk loop of the dense-tile unit) -- still bit-identical to the CSR-order oracle."""
+    rp, col = gen()
+    g = Graph(rp, col, dev, force_type=force)
+    h = hcspmm.plan_header(g.row_nzr)
+    assert (h.n_dense > 0 and h.n_tasks == 0) if force else (h.n_dense == 0)
+    if force and name != "planted_dense":
+        assert h.max_dense_k > 64
+    X = np.random.default_rng(2).standard_normal((g.N, D)).astype(np.float32)
+    _check(oracle_mod, g, X, g.forward(_t(X, dev)), exact_bits=bool(force))
 
 
 @pytest.mark.parametrize("rule", [0, 1, 2])

@@ -25,6 +25,14 @@ inline int classify(int32_t size, uint32_t nnz, int32_t num, int rule) {
   const float dens = (float)nnz / (float)(num * HCSPMM_BLK_H * HCSPMM_BLK_W);
   const double t2 = (double)dens * 6.578043;
   const double logit = (t1 - t2) - 3.14922857;
+  if (rule == HCSPMM_RULE_MI355X) {
+    // refit on MI355X (all embedding widths pooled; profiles/r01/classifier_refit.json): on this chip
+    // the dense-tile path wins far beyond the 3090's boundary, because it moves uniq*D bytes instead
+    // of nnz*D and its per-window overhead is lower than 16 per-row tasks
+    const double z = (double)((float)size) * 0.021636670118575098 - (double)dens * 15.956873035536201 -
+                     0.07433807190619739;
+    return z > 0 ? 0 : 1;
+  }
   switch (rule) {
     case HCSPMM_RULE_INTENDED: return logit > 0 ? 0 : 1;
     case HCSPMM_RULE_INTENDED_GUARD: return (size > 32 || logit > 0) ? 0 : 1;
@@ -78,7 +86,7 @@ extern "C" int hcspmm_preprocess_host(const int32_t* rowptr, const int32_t* col,
                                       int32_t* edgeToRow, int32_t* hybrid_type) {
   if (N < 0 || E < 0 || !rowptr) return HCSPMM_EINVAL;
   if (E > 0 && (!col || !edgeToColumn)) return HCSPMM_EINVAL;  // edgeToRow may be NULL (skipped)
-  if (rule < HCSPMM_RULE_INTENDED || rule > HCSPMM_RULE_AS_SHIPPED) return HCSPMM_EINVAL;
+  if (rule < HCSPMM_RULE_INTENDED || rule > HCSPMM_RULE_MI355X) return HCSPMM_EINVAL;
   if (N > INT32_MAX - 16 || E > INT32_MAX) return HCSPMM_ERANGE;
   const int64_t W = (N + HCSPMM_BLK_H - 1) / HCSPMM_BLK_H;
   if (W > 0 && (!blockPartition || !hybrid_type)) return HCSPMM_EINVAL;

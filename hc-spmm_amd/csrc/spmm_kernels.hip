@@ -139,7 +139,7 @@ __device__ __forceinline__ void dense_unit(const float* __restrict__ X, float* _
   for (int kb = 0; kb < K4; kb += 16) {
     const int myU = (kb * 4 + lane < K4 * 4) ? U[kb * 4 + lane] : -1;
     const int steps = min(16, K4 - kb);
-    constexpr int B = HCSPMM_DENSE_B;
+    constexpr int B = HCSPMM_DENSE_B * (4 / VEC);  // same bytes in flight per lane whatever the panel width
     for (int t0 = 0; t0 < steps; t0 += B) {
       vec_t x[B];
       float a[B];
@@ -173,6 +173,11 @@ __device__ __forceinline__ void dense_unit(const float* __restrict__ X, float* _
     }
   }
 }
+
+// Floats per lane on the dense-tile path: a panel is 16*DVEC feature columns, so DVEC shrinks with
+// the embedding width (L*VEC >= D): D <= 16 -> 1, D <= 32 -> 2, else VEC.  A panel wider than D would
+// idle MFMA lanes and issue MFMAs for columns that do not exist.
+constexpr int dense_vec(int L, int VEC) { return (L * VEC / 16 < 1) ? 1 : (L * VEC / 16 < VEC ? L * VEC / 16 : VEC); }
 
 // ------------------------------------------------------------------------------------------
 // Planned hybrid kernel: ONE launch covers both sub-paths (as the reference's single launch
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(kThreads, MINW) void hybrid_plan_kernel(PlanArgs a)
     const int4 d = reinterpret_cast<const int4*>(a.plan + a.off_dense_index)[di];
     const int* U = a.plan + a.off_dense_pack + d.y;
     const unsigned long long* masks = reinterpret_cast<const unsigned long long*>(U + 4 * d.z);
-    dense_unit<VEC>(a.X, a.Z, U, masks, d.z, d.x, panel, a.N, a.D, lane);
+    dense_unit<dense_vec(L, VEC)>(a.X, a.Z, U, masks, d.z, d.x, panel, a.N, a.D, lane);
   }
 }
 
@@ -352,7 +357,8 @@ static hipError_t launch_plan_LV(const PlanArgs& a, hipStream_t stream) {
   b.n_wide = (R > 1) ? a.n_wide : 0;  // with one lane group per wave a wide task is an ordinary one
   b.wide_wgs = (b.n_wide + kWaves - 1) / kWaves;
   b.sparse_wgs = b.wide_wgs + (a.n_tasks - b.n_wide + kWaves * R - 1) / (kWaves * R);
-  b.n_panels = (a.D + 16 * VEC - 1) / (16 * VEC);
+  constexpr int DVEC = dense_vec(L, VEC);
+  b.n_panels = (a.D + 16 * DVEC - 1) / (16 * DVEC);
   const long long dense_units = (long long)a.n_dense * b.n_panels;
   const long long dense_wgs = (dense_units + kWaves - 1) / kWaves;
   const long long grid = (long long)b.sparse_wgs + dense_wgs;

@@ -14,7 +14,7 @@ import threading
 
 import torch
 
-from .capi import (Header, PlanParams, RULE_AS_SHIPPED, RULE_INTENDED, RULE_INTENDED_GUARD, check, lib)
+from .capi import (Header, PlanParams, RULE_AS_SHIPPED, RULE_INTENDED, RULE_INTENDED_GUARD, RULE_MI355X, check, lib)
 
 __all__ = [
     "preprocess", "forward", "forward_more", "forward_fixed32", "forward_fixed64", "forward_fixed32_fused",
@@ -22,7 +22,7 @@ __all__ = [
     "backward_fixed32", "backward_fixed32_fused", "backward_final_fused", "backward_fixed64",
     "backward_fixed64_fused", "backward_final_fused_64", "backward_GIN_final_fused", "loi_reorder",
     "apply_permutation", "plan_header", "forward_rect", "wide_threshold", "build_plan", "set_default_rule", "RULE_INTENDED", "RULE_INTENDED_GUARD",
-    "RULE_AS_SHIPPED",
+    "RULE_AS_SHIPPED", "RULE_MI355X",
 ]
 
 _DEFAULT_RULE = int(os.environ.get("HCSPMM_RULE", RULE_INTENDED))

@@ -8,6 +8,7 @@ LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "csrc", "libhcspmm.so"))
 RULE_INTENDED = 0
 RULE_INTENDED_GUARD = 1
 RULE_AS_SHIPPED = 2
+RULE_MI355X = 3
 
 OK, EINVAL, ENOMEM, EPLAN, EHIP, EWORKSPACE, ERANGE = 0, -1, -2, -3, -4, -5, -6
 

@@ -41,6 +41,9 @@ extern "C" {
 #define HCSPMM_RULE_INTENDED 0       /* logit > 0 -> sparse-row(0) else dense-tile(1); paper p.7, K.cu:261 w/o guard */
 #define HCSPMM_RULE_INTENDED_GUARD 1 /* K.cu:261 literally: size > 32 || logit > 0 -> 0 */
 #define HCSPMM_RULE_AS_SHIPPED 2     /* K.cu:262 literally: float used as bool */
+#define HCSPMM_RULE_MI355X 3         /* same two features, coefficients refit on MI355X with the paper's procedure
+                                        against THIS library's two sub-paths (tools/refit_classifier.py,
+                                        profiles/r01/classifier_refit.json); not a reference output */
 
 const char* hcspmm_strerror(int code);
 int hcspmm_abi_version(void);

@@ -57,7 +57,7 @@ GRAPHS = [
 
 
 @pytest.mark.parametrize("name,gen", GRAPHS, ids=[g[0] for g in GRAPHS])
-@pytest.mark.parametrize("rule", [0, 1, 2])
+@pytest.mark.parametrize("rule", [0, 1, 2, 3])
 def test_preprocess_bit_exact_vs_oracle(oracle_mod, name, gen, rule):
     rp, col = gen()
     want = oracle_mod.preprocess(rp, col, rule)

@@ -154,9 +154,11 @@ __device__ __forceinline__ void dense_unit(const float* __restrict__ X, float* _
       }
 #pragma unroll
       for (int u = 0; u < B; ++u) {
+        if (t0 + u < steps) {  // wave-uniform: no MFMA issue slots for the padding of a short batch
 #pragma unroll
-        for (int q = 0; q < VEC; ++q)
-          acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], vget(x[u], q), acc[q], 0, 0, 0);
+          for (int q = 0; q < VEC; ++q)
+            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], vget(x[u], q), acc[q], 0, 0, 0);
+        }
       }
     }
   }

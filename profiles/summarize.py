@@ -2,10 +2,11 @@
 """Summarise rocprofv3 CSV output (gpurun_out/prof/<pass>/...) into profiles/<round>/ and refresh
 profiles/traffic.json, which bench.py reads for roofline.traffic.
 
-  python profiles/summarize.py gpurun_out/prof profiles/r01 reddit_d128
+  python profiles/summarize.py gpurun_out/prof_round/reddit_d128 profiles/r01 reddit_d128
 
 Passes expected under the input dir: trace (--kernel-trace --stats), fetch (--pmc FETCH_SIZE),
-write (--pmc WRITE_SIZE), l2 (--pmc TCC_HIT_sum TCC_MISS_sum) -- each its own run, as
+write (--pmc WRITE_SIZE), l2 (--pmc TCC_HIT_sum TCC_MISS_sum), mfma (--pmc SQ_VALU_MFMA_BUSY_CYCLES
+GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES) -- each its own run (tools/profile_round.sh), as
 MI355X_MICROARCH.md prescribes (FETCH_SIZE and WRITE_SIZE do not fit one pass).
 Corrections applied (same guide, section HBM): counters are in KiB; on gfx950 FETCH_SIZE reports
 half of the bytes of wide coalesced reads -> doubled; WRITE_SIZE is exact for 16-B stores.
@@ -38,7 +39,7 @@ def main():
                 out["kernels"][r["Name"]] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
                                              "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"])}
     pmc = {}
-    for p in ("fetch", "write", "l2"):
+    for p in ("fetch", "write", "l2", "mfma"):
         for (k, c), v in counters(os.path.join(src, p)).items():
             if "hcspmm" in k:
                 pmc.setdefault(k, {})[c] = v
@@ -53,6 +54,13 @@ def main():
         out["write_bytes"] = write_b
         if "TCC_HIT_sum" in m:
             out["l2_hit_rate"] = m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"])
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in m and m.get("GRBM_GUI_ACTIVE"):
+            # rocprofv3's MfmaUtil expression: sum over SIMDs of MFMA-busy cycles / (GPU-active cycles * SIMDs);
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs (MI355X_MICROARCH.md, DVFS note) -> divide by 8
+            simds = 256 * 4
+            active = m["GRBM_GUI_ACTIVE"] / 8.0
+            out["mfma_util_percent"] = 100.0 * m["SQ_VALU_MFMA_BUSY_CYCLES"] / (active * simds)
+            out["mfma_flops_per_launch"] = m.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0) * 512.0
         tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic.json")
         t = json.load(open(tpath)) if os.path.exists(tpath) else {}
         t[key] = fetch_b + write_b

@@ -106,7 +106,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("name,gen,split_free", CASES, ids=[c[0] for c in CASES])
-@pytest.mark.parametrize("D", [32, 128, 256, 16, 22, 7, 96])
+@pytest.mark.parametrize("D", [32, 128, 256, 16, 22, 7, 96, 1, 300])
 def test_forward_parity_planned(oracle_mod, dev, name, gen, split_free, D):
     rp, col = gen()
     g = Graph(rp, col, dev)

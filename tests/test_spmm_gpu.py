@@ -274,3 +274,37 @@ def test_forward_is_hip_graph_capturable(oracle_mod, dev):
     graph.replay()
     torch.cuda.synchronize()
     _check(oracle_mod, g, 2 * X, Z)
+
+
+def test_offsets_beyond_2_to_31_elements(dev):
+    """X and Z with more than 2^31 elements (BASELINE config 5 territory: 16 M nodes x 128): row offsets
+    must be 64-bit.  9 M nodes x 256 columns = 2.3e9 elements (9.2 GB each); checked with exact
+    integer checksums on both sub-paths (columns chosen from the top of the id range)."""
+    N, D = 9_000_000, 256
+    rng = np.random.default_rng(5)
+    # sparse rows: 4 entries each, biased to high column ids; plus planted dense windows at the end
+    deg = np.full(N, 4, np.int64)
+    cols = (N - 1 - rng.integers(0, N // 3, size=4 * N)).astype(np.int64).reshape(N, 4)
+    cols.sort(axis=1)
+    for k in range(1, 4):  # make entries unique within a row
+        cols[:, k] = np.maximum(cols[:, k], cols[:, k - 1] + 1)
+    cols = np.minimum(cols, N - 1)
+    first_planted = (N // 16 - 100_000) * 16  # the last 100 K windows: all 16 rows share the window's first row's columns
+    cols[first_planted:] = np.repeat(cols[first_planted::16], 16, axis=0)
+    keep = np.ones((N, 4), bool)
+    keep[:, 1:] = cols[:, 1:] > cols[:, :-1]
+    rp = np.concatenate([[0], np.cumsum(keep.sum(1))]).astype(np.int32)
+    col = cols[keep].astype(np.int32)
+    g = Graph(rp, col, dev)
+    h = hcspmm.plan_header(g.row_nzr)
+    assert h.n_dense >= 99_000 and h.n_tasks > 7_000_000  # planted windows go dense, the rest sparse
+    ids = torch.arange(N, device=dev, dtype=torch.float32) % 1021
+    X = ids[:, None].expand(N, D).contiguous()
+    assert X.numel() > 2 ** 31
+    Z = g.forward(X)
+    want = np.zeros(N, np.float64)
+    np.add.at(want, np.repeat(np.arange(N), np.diff(rp)), (col.astype(np.int64) % 1021).astype(np.float64))
+    want_t = torch.from_numpy(want.astype(np.float32)).to(dev)
+    assert torch.equal(Z[:, 0], want_t) and torch.equal(Z[:, D - 1], want_t) and torch.equal(Z[:, 100], want_t)
+    del X, Z
+    torch.cuda.empty_cache()

@@ -14,21 +14,46 @@
 
 #include "hcspmm.h"
 
+namespace {
+int loi_reorder_impl(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, int variant, int32_t* perm_out,
+                     int32_t* group_sizes_out, int64_t* n_groups_out);
+}
+
 extern "C" int hcspmm_loi_reorder(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, int32_t* perm_out,
                                   int32_t* group_sizes_out, int64_t* n_groups_out) {
+  return loi_reorder_impl(rowptr, col, N, E, HCSPMM_LOI_NEW_DIRECT, perm_out, group_sizes_out, n_groups_out);
+}
+
+extern "C" int hcspmm_loi_reorder_variant(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, int variant,
+                                          int32_t* perm_out, int32_t* group_sizes_out, int64_t* n_groups_out) {
+  if (variant != HCSPMM_LOI_NEW_DIRECT && variant != HCSPMM_LOI_NEW) return HCSPMM_EINVAL;
+  return loi_reorder_impl(rowptr, col, N, E, variant, perm_out, group_sizes_out, n_groups_out);
+}
+
+namespace {
+int loi_reorder_impl(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, int variant, int32_t* perm_out,
+                     int32_t* group_sizes_out, int64_t* n_groups_out) {
   if (N < 0 || E < 0 || !rowptr || (N > 0 && !perm_out) || (E > 0 && !col)) return HCSPMM_EINVAL;
   if (N > INT32_MAX - 16 || E > INT32_MAX) return HCSPMM_ERANGE;
   for (int64_t e = 0; e < E; ++e)
     if (col[e] < 0 || col[e] >= N) return HCSPMM_EINVAL;
 
-  // in-CSR, in-neighbour lists ascending (row-major scan)
-  std::vector<int32_t> rowptr_in((size_t)N + 1, 0), col_in((size_t)E);
-  for (int64_t e = 0; e < E; ++e) rowptr_in[(size_t)col[e] + 1]++;
-  for (int64_t i = 0; i < N; ++i) rowptr_in[(size_t)i + 1] += rowptr_in[(size_t)i];
-  {
-    std::vector<int32_t> fill(rowptr_in.begin(), rowptr_in.end() - 1);
+  // rows that reference a column: the in-CSR (in-neighbour lists ascending, row-major scan) for
+  // reorder_plus_new_direct; reorder_plus_new (LOI.cpp:505-658) walks the column's OWN out-list
+  // instead (LOI.cpp:556-557), i.e. it assumes a symmetric graph
+  std::vector<int32_t> rowptr_in_v, col_in_v;
+  const int32_t* rowptr_in = rowptr;
+  const int32_t* col_in = col;
+  if (variant == HCSPMM_LOI_NEW_DIRECT) {
+    rowptr_in_v.assign((size_t)N + 1, 0);
+    col_in_v.resize((size_t)E);
+    for (int64_t e = 0; e < E; ++e) rowptr_in_v[(size_t)col[e] + 1]++;
+    for (int64_t i = 0; i < N; ++i) rowptr_in_v[(size_t)i + 1] += rowptr_in_v[(size_t)i];
+    std::vector<int32_t> fill(rowptr_in_v.begin(), rowptr_in_v.end() - 1);
     for (int64_t r = 0; r < N; ++r)
-      for (int32_t e = rowptr[r]; e < rowptr[r + 1]; ++e) col_in[(size_t)fill[(size_t)col[e]]++] = (int32_t)r;
+      for (int32_t e = rowptr[r]; e < rowptr[r + 1]; ++e) col_in_v[(size_t)fill[(size_t)col[e]]++] = (int32_t)r;
+    rowptr_in = rowptr_in_v.data();
+    col_in = col_in_v.data();
   }
 
   std::vector<uint8_t> visit((size_t)N, 0);
@@ -120,6 +145,7 @@ extern "C" int hcspmm_loi_reorder(const int32_t* rowptr, const int32_t* col, int
   if (n_groups_out) *n_groups_out = (int64_t)groups.size();
   return p == N ? HCSPMM_OK : HCSPMM_EINVAL;
 }
+}  // namespace
 
 extern "C" int hcspmm_apply_permutation(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E,
                                         const int32_t* perm, int32_t* rowptr_out, int32_t* col_out) {

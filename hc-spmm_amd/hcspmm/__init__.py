@@ -276,8 +276,9 @@ backward_final_fused_64 = forward_final_fused_64
 backward_GIN_final_fused = forward_GIN_final_fused
 
 
-def loi_reorder(row_pointers, column_index):
-    """LOI layout reorder (LOI.cpp:660-805 + main's output order) -> (perm[N], group_sizes)."""
+def loi_reorder(row_pointers, column_index, variant="new_direct"):
+    """LOI layout reorder (LOI.cpp:660-805 + main's output order) -> (perm[N], group_sizes).
+    variant "new" = reorder_plus_new (LOI.cpp:505-658, symmetric-graph form)."""
     L = lib()
     rp = _i32_host(row_pointers)
     col = _i32_host(column_index)
@@ -285,7 +286,8 @@ def loi_reorder(row_pointers, column_index):
     perm = torch.empty(N, dtype=torch.int32)
     gs = torch.empty(max(N, 1), dtype=torch.int32)
     ng = ctypes.c_int64(0)
-    check(L.hcspmm_loi_reorder(_ptr(rp), _ptr(col), N, E, _ptr(perm), _ptr(gs), ctypes.byref(ng)))
+    check(L.hcspmm_loi_reorder_variant(_ptr(rp), _ptr(col), N, E, {"new_direct": 0, "new": 1}[variant], _ptr(perm), _ptr(gs),
+                                       ctypes.byref(ng)))
     return perm, gs[:ng.value].clone()
 
 

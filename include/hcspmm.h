@@ -192,6 +192,15 @@ int hcspmm_loi_reorder(const int32_t* row_pointers_h, const int32_t* column_inde
                        int64_t num_edges, int32_t* perm_out_h, int32_t* group_sizes_out_h,
                        int64_t* n_groups_out);
 
+/* The same with the reference's other un-windowed variant selectable: HCSPMM_LOI_NEW restates
+ * reorder_plus_new (LOI.cpp:505-658), which finds candidate rows through the column's own out-list
+ * (it assumes a symmetric graph); on symmetric input both variants give the same order. */
+#define HCSPMM_LOI_NEW_DIRECT 0
+#define HCSPMM_LOI_NEW 1
+int hcspmm_loi_reorder_variant(const int32_t* row_pointers_h, const int32_t* column_index_h, int64_t num_nodes,
+                               int64_t num_edges, int variant, int32_t* perm_out_h, int32_t* group_sizes_out_h,
+                               int64_t* n_groups_out);
+
 /* Apply a LOI permutation to a CSR graph (the step missing from the reference repository,
  * SURVEY.md section 1 L0): new id of old vertex perm[i] is i; rows AND columns are relabelled,
  * columns re-sorted ascending.  Outputs have the sizes of the inputs. */

@@ -36,11 +36,18 @@ def _residual(cols_sorted, out_nbrs):
     return sorted(cols_sorted + resi), resi
 
 
-def reorder_new_direct(rowptr, col, N):
+def reorder_new(rowptr, col, N):
+    """reorder_plus_new (LOI.cpp:505-658): identical to the _direct variant except that the rows
+    "referencing" a column c are taken from c's OWN out-list (LOI.cpp:556-557, :606-607) -- correct
+    only for symmetric graphs, where both variants coincide."""
+    return reorder_new_direct(rowptr, col, N, symmetric_shortcut=True)
+
+
+def reorder_new_direct(rowptr, col, N, symmetric_shortcut=False):
     """-> (groups: list[list[int]], visit: list[bool]); LOI.cpp:660-805."""
     rowptr = [int(x) for x in rowptr]
     col = [int(x) for x in col]
-    rowptr_in, col_in = build_in_csr(rowptr, col, N)
+    rowptr_in, col_in = (rowptr, col) if symmetric_shortcut else build_in_csr(rowptr, col, N)
     deg = [rowptr[i + 1] - rowptr[i] for i in range(N)]
     front = [i for i in range(N) if deg[i] > 0]                       # :665-670
     visit = [False] * N

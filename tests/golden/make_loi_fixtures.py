@@ -70,7 +70,9 @@ if __name__ == "__main__":
     out_dir = os.path.dirname(os.path.abspath(__file__))
     for name, (rp, col) in cases():
         sizes, members, order = run_ref(rp, col)
+        sizes_n, members_n, order_n = run_ref(rp, col, "new")  # reorder_plus_new (LOI.cpp:505-658)
         assert sorted(order.tolist()) == list(range(len(rp) - 1)), name
         np.savez_compressed(os.path.join(out_dir, "loi_%s.npz" % name), row_pointers=rp, column_index=col,
-                            group_sizes=sizes, group_members=members, order=order)
+                            group_sizes=sizes, group_members=members, order=order,
+                            group_sizes_new=sizes_n, group_members_new=members_n, order_new=order_n)
         print(name, "N", len(rp) - 1, "E", len(col), "groups", len(sizes), "full", int((sizes == 16).sum()))

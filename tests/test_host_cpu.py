@@ -202,6 +202,10 @@ def test_loi_reorder_matches_reference_golden(path):
     perm, sizes = hcspmm.loi_reorder(_t(g["row_pointers"]), _t(g["column_index"]))
     assert np.array_equal(sizes.numpy(), g["group_sizes"])
     assert np.array_equal(perm.numpy(), g["order"])
+    perm, sizes = hcspmm.loi_reorder(_t(g["row_pointers"]), _t(g["column_index"]), variant="new")
+    assert np.array_equal(sizes.numpy(), g["group_sizes_new"]) and np.array_equal(perm.numpy(), g["order_new"])
+    if "sym" in path:  # symmetric graphs: both variants coincide
+        assert np.array_equal(g["order"], g["order_new"])
 
 
 def test_loi_reorder_matches_oracle_on_larger_graph():

@@ -134,6 +134,9 @@ def test_loi_oracle_matches_reference_golden(path):
     assert [len(x) for x in groups] == g["group_sizes"].tolist()
     assert np.array_equal(np.concatenate([np.asarray(x, np.int32) for x in groups]), g["group_members"])
     assert np.array_equal(loi_oracle.final_order(groups, visit), g["order"])
+    groups, visit = loi_oracle.reorder_new(rp, col, len(rp) - 1)  # the other un-windowed variant
+    assert [len(x) for x in groups] == g["group_sizes_new"].tolist()
+    assert np.array_equal(loi_oracle.final_order(groups, visit), g["order_new"])
 
 
 def test_golden_csr_fixture_is_scipy_tocsr_semantics():

@@ -146,12 +146,20 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the hot path has no CPU fallback", file=sys.stderr)
         sys.exit(2)
+    # HCSPMM_BENCH_REHEARSAL=1: every rank on GPU 0 with gloo collectives -- lets the N > 1 plumbing run
+    # on a one-GPU box (numbers from it are meaningless and are labelled as such)
+    rehearsal = os.environ.get("HCSPMM_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import hcspmm
     from hcspmm.sharded import ShardedGraph, ShardedSpMM
@@ -201,8 +209,9 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev_pairs])) if ev_pairs else float("nan")
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    etot = torch.tensor([float(E)], dtype=torch.float64, device=dev)
+    red_dev = torch.device("cpu") if rehearsal else dev
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    etot = torch.tensor([float(E)], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(etot, op=dist.ReduceOp.SUM)
@@ -215,7 +224,7 @@ def main():
         achieved = b_alg / (kern_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and world == 1:  # measured for the one-GPU launch only
             try:
                 traffic = json.load(open(tpath)).get("%s_d%d" % (args.workload, D))
             except Exception:
@@ -225,7 +234,8 @@ def main():
             "value": total_edges * D / (elapsed / args.steps),
             "unit": "edge*dim/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo -- not a measurement)" if rehearsal else ""),
             "config": {"workload": "%s: %s; %d nodes / %d stored entries per GPU, dim %d"
                                    % (args.workload, desc, n_local, E, D),
                        "nodes_per_gpu": n_local, "entries_per_gpu": E, "dim": D, "parallelism": "row-block shard x%d + all-gather(X)" % world,

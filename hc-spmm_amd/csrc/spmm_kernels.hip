@@ -64,7 +64,8 @@ constexpr int kThreads = kWaves * 64;
 // ------------------------------------------------------------------------------------------
 template <int L, int VEC, bool WIDE, int UMAX = HCSPMM_SPARSE_U>
 __device__ __forceinline__ void sparse_task(const float* __restrict__ X, float* __restrict__ dst,
-                                            const int* __restrict__ col, int e0, int n, int D, int lane) {
+                                            const int* __restrict__ col, int e0, int n, int D, int c0, int cend,
+                                            int lane) {
   typedef typename VecT<VEC>::type vec_t;
   constexpr int U = (L < UMAX) ? L : UMAX;  // loads in flight per lane
   // WIDE: the whole wave owns ONE task (e0, n wave-uniform); per 64-entry super-chunk lane i holds
@@ -81,9 +82,9 @@ __device__ __forceinline__ void sparse_task(const float* __restrict__ X, float* 
   }
   nmax = __builtin_amdgcn_readfirstlane(nmax);
 
-  for (int pbase = 0; pbase < D; pbase += L * VEC) {
+  for (int pbase = c0; pbase < cend; pbase += L * VEC) {  // feature columns [c0, cend) of the rows
     const int c = pbase + s * VEC;
-    const bool cok = c < D;
+    const bool cok = c < cend;
     vec_t acc = vzero<VEC>();
     // the next chunk's indices are requested before the current chunk's rows, so a chunk costs one
     // memory round trip instead of two
@@ -176,11 +177,6 @@ __device__ __forceinline__ void dense_unit(const float* __restrict__ X, float* _
   }
 }
 
-// Floats per lane on the dense-tile path: a panel is 16*DVEC feature columns, so DVEC shrinks with
-// the embedding width (L*VEC >= D): D <= 16 -> 1, D <= 32 -> 2, else VEC.  A panel wider than D would
-// idle MFMA lanes and issue MFMAs for columns that do not exist.
-constexpr int dense_vec(int L, int VEC) { return (L * VEC / 16 < 1) ? 1 : (L * VEC / 16 < VEC ? L * VEC / 16 : VEC); }
-
 // ------------------------------------------------------------------------------------------
 // Planned hybrid kernel: ONE launch covers both sub-paths (as the reference's single launch
 // does, K.cu:960/1039) -- workgroups [0, wide_wgs) run wide sparse tasks, [wide_wgs, sparse_wgs) ordinary ones, the rest dense units.
@@ -191,35 +187,47 @@ template <int L, int VEC, int UNROLL, int MINW>
 __global__ __launch_bounds__(kThreads, MINW) void hybrid_plan_kernel(PlanArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if ((int)blockIdx.x < a.wide_wgs) {
-    // wide tasks: the a.n_wide longest tasks, one per wave
-    const int tid = (int)blockIdx.x * kWaves + wave;
-    if (tid >= a.n_wide) return;
-    const int4 t = reinterpret_cast<const int4*>(a.plan + a.off_tasks)[tid];
-    float* dst = (t.w < 0) ? a.Z + (size_t)t.x * (size_t)a.D : a.partial + (size_t)t.w * (size_t)a.D;
-    sparse_task<L, VEC, true, UNROLL>(a.X, dst, a.col, __builtin_amdgcn_readfirstlane(t.y),
-                              __builtin_amdgcn_readfirstlane(t.z), a.D, lane);
-  } else if ((int)blockIdx.x < a.sparse_wgs) {
-    constexpr int R = 64 / L;
-    const int g = lane / L;
-    const int tid = a.n_wide + (((int)blockIdx.x - a.wide_wgs) * kWaves + wave) * R + g;
-    int e0 = 0, n = 0;
-    float* dst = nullptr;
-    if (tid < a.n_tasks) {
+  if ((int)blockIdx.x < a.sparse_wgs) {
+    // column-panel-major: every sparse task runs once per panel of a.panel_cols feature columns, and
+    // all workgroups of panel p precede those of panel p+1, so at any time the gathers touch one
+    // 128-byte slice of the X rows -- four times as many distinct rows fit the per-XCD L2
+    const int p = (int)blockIdx.x / a.sparse_wgs_pp;
+    const int b = (int)blockIdx.x - p * a.sparse_wgs_pp;
+    const int c0 = p * a.panel_cols;
+    const int cend = min(a.D, c0 + a.panel_cols);
+    if (b < a.wide_wgs) {
+      // wide tasks: the a.n_wide longest tasks, one per wave
+      const int tid = b * kWaves + wave;
+      if (tid >= a.n_wide) return;
       const int4 t = reinterpret_cast<const int4*>(a.plan + a.off_tasks)[tid];
-      e0 = t.y;
-      n = t.z;
-      dst = (t.w < 0) ? a.Z + (size_t)t.x * (size_t)a.D : a.partial + (size_t)t.w * (size_t)a.D;
+      float* dst = (t.w < 0) ? a.Z + (size_t)t.x * (size_t)a.D : a.partial + (size_t)t.w * (size_t)a.D;
+      sparse_task<L, VEC, true, UNROLL>(a.X, dst, a.col, __builtin_amdgcn_readfirstlane(t.y),
+                                        __builtin_amdgcn_readfirstlane(t.z), a.D, c0, cend, lane);
+    } else {
+      constexpr int R = 64 / L;
+      const int g = lane / L;
+      const int tid = a.n_wide + ((b - a.wide_wgs) * kWaves + wave) * R + g;
+      int e0 = 0, n = 0;
+      float* dst = nullptr;
+      if (tid < a.n_tasks) {
+        const int4 t = reinterpret_cast<const int4*>(a.plan + a.off_tasks)[tid];
+        e0 = t.y;
+        n = t.z;
+        dst = (t.w < 0) ? a.Z + (size_t)t.x * (size_t)a.D : a.partial + (size_t)t.w * (size_t)a.D;
+      }
+      sparse_task<L, VEC, false, UNROLL>(a.X, dst, a.col, e0, n, a.D, c0, cend, lane);
     }
-    sparse_task<L, VEC, false, UNROLL>(a.X, dst, a.col, e0, n, a.D, lane);
   } else {
     const int unit = ((int)blockIdx.x - a.sparse_wgs) * kWaves + wave;
     if (unit >= a.n_dense * a.n_panels) return;
-    const int di = unit / a.n_panels, panel = unit - di * a.n_panels;
+    const int panel = unit / a.n_dense, di = unit - panel * a.n_dense;  // panel-major, like the sparse region
     const int4 d = reinterpret_cast<const int4*>(a.plan + a.off_dense_index)[di];
     const int* U = a.plan + a.off_dense_pack + d.y;
     const unsigned long long* masks = reinterpret_cast<const unsigned long long*>(U + 4 * d.z);
-    dense_unit<dense_vec(L, VEC)>(a.X, a.Z, U, masks, d.z, d.x, panel, a.N, a.D, lane);
+    // floats per lane on the dense-tile path (a panel is 16*dvec columns): set by the launcher from D
+    if (VEC >= 4 && a.dense_vec == 4) dense_unit<(VEC >= 4 ? 4 : 1)>(a.X, a.Z, U, masks, d.z, d.x, panel, a.N, a.D, lane);
+    else if (VEC >= 2 && a.dense_vec == 2) dense_unit<(VEC >= 2 ? 2 : 1)>(a.X, a.Z, U, masks, d.z, d.x, panel, a.N, a.D, lane);
+    else dense_unit<1>(a.X, a.Z, U, masks, d.z, d.x, panel, a.N, a.D, lane);
   }
 }
 
@@ -280,7 +288,7 @@ __global__ __launch_bounds__(kThreads) void hybrid_window_kernel(WindowArgs a) {
         n = a.rowptr[r + 1] - e0;
         dst = a.Z + (size_t)r * (size_t)a.D;
       }
-      sparse_task<L, VEC, false>(a.X, dst, a.col, e0, n, a.D, lane);
+      sparse_task<L, VEC, false>(a.X, dst, a.col, e0, n, a.D, 0, a.D, lane);
     }
     return;
   }
@@ -358,12 +366,17 @@ static hipError_t launch_plan_LV(const PlanArgs& a, hipStream_t stream) {
   PlanArgs b = a;
   b.n_wide = (R > 1) ? a.n_wide : 0;  // with one lane group per wave a wide task is an ordinary one
   b.wide_wgs = (b.n_wide + kWaves - 1) / kWaves;
-  b.sparse_wgs = b.wide_wgs + (a.n_tasks - b.n_wide + kWaves * R - 1) / (kWaves * R);
-  constexpr int DVEC = dense_vec(L, VEC);
-  b.n_panels = (a.D + 16 * DVEC - 1) / (16 * DVEC);
+  b.sparse_wgs_pp = b.wide_wgs + (a.n_tasks - b.n_wide + kWaves * R - 1) / (kWaves * R);
+  const int n_col_panels = (a.D + a.panel_cols - 1) / a.panel_cols;
+  b.sparse_wgs = b.sparse_wgs_pp * n_col_panels;
+  if (b.sparse_wgs_pp == 0) b.sparse_wgs_pp = 1;  // divisor in the kernel
+  // dense-tile panel width: 16*dense_vec columns -- never wider than the embedding (idle MFMA lanes)
+  b.dense_vec = (a.D >= 64) ? VEC : (a.D >= 32 ? (VEC < 2 ? VEC : 2) : 1);
+  if (b.dense_vec > VEC) b.dense_vec = VEC;
+  b.n_panels = (a.D + 16 * b.dense_vec - 1) / (16 * b.dense_vec);
   const long long dense_units = (long long)a.n_dense * b.n_panels;
   const long long dense_wgs = (dense_units + kWaves - 1) / kWaves;
-  const long long grid = (long long)b.sparse_wgs + dense_wgs;
+  const long long grid = (long long)b.sparse_wgs_pp * n_col_panels + dense_wgs;
   if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
   if (grid > 0) {
     if (a.latency_bound)
@@ -398,7 +411,7 @@ static int pick_L(int D, int VEC) {
 }
 
 #define HCSPMM_DISPATCH_L(FN, VEC, ARGS, STREAM)            \
-  switch (pick_L((ARGS).D, VEC)) {                          \
+  switch (pick_L((ARGS).panel_cols, VEC)) {                 \
     case 4:  return FN<4, VEC>(ARGS, STREAM);               \
     case 8:  return FN<8, VEC>(ARGS, STREAM);               \
     case 16: return FN<16, VEC>(ARGS, STREAM);              \
@@ -412,10 +425,19 @@ hipError_t launch_plan(const PlanArgs& a, int vec, hipStream_t stream) {
   HCSPMM_DISPATCH_L(launch_plan_LV, 1, a, stream)
 }
 
+#define HCSPMM_DISPATCH_LW(FN, VEC, ARGS, STREAM)           \
+  switch (pick_L((ARGS).D, VEC)) {                          \
+    case 4:  return FN<4, VEC>(ARGS, STREAM);               \
+    case 8:  return FN<8, VEC>(ARGS, STREAM);               \
+    case 16: return FN<16, VEC>(ARGS, STREAM);              \
+    case 32: return FN<32, VEC>(ARGS, STREAM);              \
+    default: return FN<64, VEC>(ARGS, STREAM);              \
+  }
+
 hipError_t launch_window(const WindowArgs& a, int vec, hipStream_t stream) {
-  if (vec == 4) { HCSPMM_DISPATCH_L(launch_window_LV, 4, a, stream) }
-  if (vec == 2) { HCSPMM_DISPATCH_L(launch_window_LV, 2, a, stream) }
-  HCSPMM_DISPATCH_L(launch_window_LV, 1, a, stream)
+  if (vec == 4) { HCSPMM_DISPATCH_LW(launch_window_LV, 4, a, stream) }
+  if (vec == 2) { HCSPMM_DISPATCH_LW(launch_window_LV, 2, a, stream) }
+  HCSPMM_DISPATCH_LW(launch_window_LV, 1, a, stream)
 }
 
 }  // namespace hcspmm

@@ -70,10 +70,10 @@ class ShardedGraph:
 class ShardedSpMM:
     """Z_local = A[rows_p, :] @ all_gather(X_local).
 
-    local_spmm(X_full[P*pad_rows, D]) -> Z_local[n_local, D] is the local operator.  With
-    n_panels > 1 the feature columns are cut into panels: the gather of panel k+1 runs on a side
-    stream while the product of panel k runs on the main stream (the gather and the product are of
-    the same order on xGMI vs HBM) -- used only on CUDA devices.
+    local_spmm(X_full[P*pad_rows, D]) -> Z_local[n_local, D] is the local operator.  The gather and the
+    product run back to back on the caller's stream; cutting the feature columns into panels so that
+    the gather of panel k+1 overlaps the product of panel k is the planned next step (the gather is
+    the longer of the two on xGMI).
     """
 
     def __init__(self, graph, local_spmm, group=None):
@@ -91,7 +91,13 @@ class ShardedSpMM:
             pad[:g.n_local] = X_local
             X_local = pad
         full = torch.empty((g.world_size * g.pad_rows, D), dtype=X_local.dtype, device=X_local.device)
-        dist.all_gather_into_tensor(full, X_local.contiguous(), group=self.group)
+        if X_local.is_cuda and dist.get_backend(self.group) != "nccl":
+            # rehearsal mode (e.g. several ranks sharing one GPU over gloo): stage through the host
+            host = torch.empty(full.shape, dtype=full.dtype)
+            dist.all_gather_into_tensor(host, X_local.contiguous().cpu(), group=self.group)
+            full.copy_(host)
+        else:
+            dist.all_gather_into_tensor(full, X_local.contiguous(), group=self.group)
         return full
 
     def forward(self, X_local):

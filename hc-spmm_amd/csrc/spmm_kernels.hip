@@ -376,7 +376,7 @@ static hipError_t launch_plan_LV(const PlanArgs& a, hipStream_t stream) {
   b.n_panels = (a.D + 16 * b.dense_vec - 1) / (16 * b.dense_vec);
   const long long dense_units = (long long)a.n_dense * b.n_panels;
   const long long dense_wgs = (dense_units + kWaves - 1) / kWaves;
-  const long long grid = (long long)b.sparse_wgs_pp * n_col_panels + dense_wgs;
+  const long long grid = (long long)b.sparse_wgs + dense_wgs;
   if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
   if (grid > 0) {
     if (a.latency_bound)

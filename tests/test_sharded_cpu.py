@@ -92,3 +92,41 @@ def test_sharded_spmm_world2_gloo(tmp_path, D):
         assert ok == 1
         covered.append((int(r0), int(r1)))
     assert covered[0][1] == covered[1][0]
+
+
+def _gpu_worker(rank, world, port, out_dir):
+    """Two ranks sharing GPU 0 (gloo collectives, host-staged gather): the REAL HIP operator as the
+    local product of the row-block shard, unequal blocks (padding + column remap)."""
+    for p in (ROOT, os.path.join(ROOT, "hc-spmm_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import hcspmm
+    import oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        rp, col = graphs.powerlaw_graph(5003, 90000, seed=11, max_degree_frac=0.3)
+        N, D = len(rp) - 1, 64
+        X = np.random.default_rng(3).standard_normal((N, D)).astype(np.float32)
+        g = ShardedGraph(rp, col, partition_rows(rp, world), rank)
+        rp_d, col_d = torch.from_numpy(g.row_pointers).to(dev), torch.from_numpy(g.column_index).to(dev)
+        outs = hcspmm.preprocess(col_d, rp_d, g.n_local, len(g.column_index), (g.n_local + 15) // 16)
+        op = ShardedSpMM(g, lambda Xf: hcspmm.forward_rect(Xf, rp_d, col_d, *outs)[0])
+        Z = op(torch.from_numpy(X[g.r0:g.r1]).to(dev)).cpu().numpy()
+        e0, e1 = rp[g.r0], rp[g.r1]
+        ok, ratio = oracle.check_spmm(Z, (rp[g.r0:g.r1 + 1] - e0).astype(np.int32), col[e0:e1], X)
+        np.save(os.path.join(out_dir, "gpu_ok_%d.npy" % rank), np.array([ok, ratio]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_spmm_two_ranks_on_one_gpu(tmp_path):
+    assert torch.cuda.is_available()
+    port = _free_port()
+    mp.spawn(_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        ok, ratio = np.load(tmp_path / ("gpu_ok_%d.npy" % r))
+        assert ok == 1, ratio

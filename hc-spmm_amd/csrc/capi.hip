@@ -23,9 +23,10 @@ int fail_hip(hipError_t e) {
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
 // widest per-lane access the operands allow
-int pick_vec(int D, const void* X, const void* Z, const void* ws) {
-  if (D % 4 == 0 && aligned(X, 16) && aligned(Z, 16) && (!ws || aligned(ws, 16))) return 4;
-  if (D % 2 == 0 && aligned(X, 8) && aligned(Z, 8) && (!ws || aligned(ws, 8))) return 2;
+int pick_vec(int D, int64_t ldx, int64_t ldz, const void* X, const void* Z, const void* ws) {
+  const int64_t all = (int64_t)D | ldx | ldz;
+  if (all % 4 == 0 && aligned(X, 16) && aligned(Z, 16) && (!ws || aligned(ws, 16))) return 4;
+  if (all % 2 == 0 && aligned(X, 8) && aligned(Z, 8) && (!ws || aligned(ws, 8))) return 2;
   return 1;
 }
 }  // namespace
@@ -98,11 +99,12 @@ extern "C" int32_t hcspmm_wide_threshold(const hcspmm_plan_header* h, int D) {
 extern "C" int hcspmm_abi_version(void) { return HCSPMM_ABI_VERSION; }
 extern "C" int hcspmm_last_hip_error(void) { return g_last_hip_error; }
 
-extern "C" int hcspmm_forward(const float* X, float* Z, const int32_t* rowptr, const int32_t* col,
+extern "C" int hcspmm_forward_strided(const float* X, int64_t ldx, float* Z, int64_t ldz, const int32_t* rowptr,
+                                      const int32_t* col,
                               const int32_t* blockPartition, const int32_t* edgeToColumn, const int32_t* edgeToRow,
                               const int32_t* hybrid_type, const int32_t* plan_d, const hcspmm_plan_header* ph,
                               int64_t N, int64_t E, int D, void* workspace, size_t workspace_bytes, void* stream_v) {
-  if (N < 0 || E < 0 || D <= 0) return HCSPMM_EINVAL;
+  if (N < 0 || E < 0 || D <= 0 || ldx < D || ldz < D) return HCSPMM_EINVAL;
   if (N == 0) return HCSPMM_OK;
   if (!X || !Z || !rowptr || (E > 0 && !col)) return HCSPMM_EINVAL;
   if (N > INT32_MAX - 16 || E > INT32_MAX) return HCSPMM_ERANGE;
@@ -116,6 +118,8 @@ extern "C" int hcspmm_forward(const float* X, float* Z, const int32_t* rowptr, c
     hcspmm::PlanArgs a;
     a.X = X;
     a.Z = Z;
+    a.ldx = (size_t)ldx;
+    a.ldz = (size_t)ldz;
     a.partial = need ? reinterpret_cast<float*>(workspace) : nullptr;
     a.col = col;
     a.plan = plan_d;
@@ -134,13 +138,15 @@ extern "C" int hcspmm_forward(const float* X, float* Z, const int32_t* rowptr, c
     a.D = D;
     a.sparse_wgs = 0;
     a.n_panels = 0;
-    e = hcspmm::launch_plan(a, pick_vec(D, X, Z, need ? workspace : nullptr), stream);
+    e = hcspmm::launch_plan(a, pick_vec(D, ldx, ldz, X, Z, need ? workspace : nullptr), stream);
   } else {
     if (plan_d || ph) return HCSPMM_EINVAL;  // both or neither
     if (!blockPartition || !hybrid_type || (E > 0 && (!edgeToColumn || !edgeToRow))) return HCSPMM_EINVAL;
     hcspmm::WindowArgs a;
     a.X = X;
     a.Z = Z;
+    a.ldx = (size_t)ldx;
+    a.ldz = (size_t)ldz;
     a.rowptr = rowptr;
     a.col = col;
     a.blockPartition = blockPartition;
@@ -149,9 +155,17 @@ extern "C" int hcspmm_forward(const float* X, float* Z, const int32_t* rowptr, c
     a.hybrid_type = hybrid_type;
     a.N = (int)N;
     a.D = D;
-    e = hcspmm::launch_window(a, pick_vec(D, X, Z, nullptr), stream);
+    e = hcspmm::launch_window(a, pick_vec(D, ldx, ldz, X, Z, nullptr), stream);
   }
   return e == hipSuccess ? HCSPMM_OK : fail_hip(e);
+}
+
+extern "C" int hcspmm_forward(const float* X, float* Z, const int32_t* rowptr, const int32_t* col,
+                              const int32_t* blockPartition, const int32_t* edgeToColumn, const int32_t* edgeToRow,
+                              const int32_t* hybrid_type, const int32_t* plan_d, const hcspmm_plan_header* ph,
+                              int64_t N, int64_t E, int D, void* workspace, size_t workspace_bytes, void* stream_v) {
+  return hcspmm_forward_strided(X, D, Z, D, rowptr, col, blockPartition, edgeToColumn, edgeToRow, hybrid_type, plan_d, ph,
+                                N, E, D, workspace, workspace_bytes, stream_v);
 }
 
 extern "C" int hcspmm_forward_fused(const float* X, float* out, float* out2, const float* weights, int64_t ldr,

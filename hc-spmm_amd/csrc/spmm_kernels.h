@@ -13,6 +13,7 @@ struct PlanArgs {
   float* partial;  // workspace: n_partials x D partial sums of split rows
   const int* col;
   const int* plan;
+  size_t ldx, ldz;  // row strides of X and Z in elements (>= D)
   int off_tasks, n_tasks;
   int off_dense_index, off_dense_pack, n_dense;
   int off_fixups, n_split_rows;
@@ -34,11 +35,12 @@ struct WindowArgs {
   const int* edgeToColumn;
   const int* edgeToRow;
   const int* hybrid_type;
+  size_t ldx, ldz;  // row strides of X and Z in elements (>= D)
   int N, D;
 };
 
-// vec = floats per lane access (4, 2 or 1): the caller guarantees D % vec == 0 and that X, Z and
-// the workspace are aligned to 4*vec bytes.
+// vec = floats per lane access (4, 2 or 1): the caller guarantees D, ldx, ldz % vec == 0 and that X, Z
+// and the workspace are aligned to 4*vec bytes.
 hipError_t launch_plan(const PlanArgs& a, int vec, hipStream_t stream);
 hipError_t launch_window(const WindowArgs& a, int vec, hipStream_t stream);
 

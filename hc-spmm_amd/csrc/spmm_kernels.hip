@@ -64,8 +64,8 @@ constexpr int kThreads = kWaves * 64;
 // ------------------------------------------------------------------------------------------
 template <int L, int VEC, bool WIDE, int UMAX = HCSPMM_SPARSE_U>
 __device__ __forceinline__ void sparse_task(const float* __restrict__ X, float* __restrict__ dst,
-                                            const int* __restrict__ col, int e0, int n, int D, int c0, int cend,
-                                            int lane) {
+                                            const int* __restrict__ col, int e0, int n, size_t ldx, int c0,
+                                            int cend, int lane) {
   typedef typename VecT<VEC>::type vec_t;
   constexpr int U = (L < UMAX) ? L : UMAX;  // loads in flight per lane
   // WIDE: the whole wave owns ONE task (e0, n wave-uniform); per 64-entry super-chunk lane i holds
@@ -99,7 +99,7 @@ __device__ __forceinline__ void sparse_task(const float* __restrict__ X, float* 
         for (int u = 0; u < U; ++u) {
           const int idx = __shfl(myidx, gbase + j + u, 64);
           v[u] = vzero<VEC>();
-          if (cok && idx >= 0) v[u] = *reinterpret_cast<const vec_t*>(X + (size_t)idx * (size_t)D + c);
+          if (cok && idx >= 0) v[u] = *reinterpret_cast<const vec_t*>(X + (size_t)idx * ldx + c);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) acc += v[u];
@@ -128,7 +128,8 @@ __device__ __forceinline__ void sparse_task(const float* __restrict__ X, float* 
 template <int VEC>
 __device__ __forceinline__ void dense_unit(const float* __restrict__ X, float* __restrict__ Z,
                                            const int* __restrict__ U, const unsigned long long* __restrict__ masks,
-                                           int K4, int window, int panel, int N, int D, int lane) {
+                                           int K4, int window, int panel, int N, int D, size_t ldx, size_t ldz,
+                                           int lane) {
   typedef typename VecT<VEC>::type vec_t;
   const int kq = lane >> 4, j = lane & 15;
   const int c = panel * 16 * VEC + j * VEC;
@@ -151,7 +152,7 @@ __device__ __forceinline__ void dense_unit(const float* __restrict__ X, float* _
         const unsigned long long m = (t < steps) ? masks[kb + t] : 0ull;
         a[u] = ((m >> lane) & 1ull) ? 1.0f : 0.0f;
         x[u] = vzero<VEC>();
-        if (cok && idx >= 0) x[u] = *reinterpret_cast<const vec_t*>(X + (size_t)idx * (size_t)D + c);
+        if (cok && idx >= 0) x[u] = *reinterpret_cast<const vec_t*>(X + (size_t)idx * ldx + c);
       }
 #pragma unroll
       for (int u = 0; u < B; ++u) {
@@ -171,7 +172,7 @@ __device__ __forceinline__ void dense_unit(const float* __restrict__ X, float* _
         vec_t o;
 #pragma unroll
         for (int q = 0; q < VEC; ++q) vset(o, q, acc[q][r]);
-        *reinterpret_cast<vec_t*>(Z + (size_t)row * (size_t)D + c) = o;
+        *reinterpret_cast<vec_t*>(Z + (size_t)row * ldz + c) = o;
       }
     }
   }
@@ -200,9 +201,9 @@ __global__ __launch_bounds__(kThreads, MINW) void hybrid_plan_kernel(PlanArgs a)
       const int tid = b * kWaves + wave;
       if (tid >= a.n_wide) return;
       const int4 t = reinterpret_cast<const int4*>(a.plan + a.off_tasks)[tid];
-      float* dst = (t.w < 0) ? a.Z + (size_t)t.x * (size_t)a.D : a.partial + (size_t)t.w * (size_t)a.D;
+      float* dst = (t.w < 0) ? a.Z + (size_t)t.x * a.ldz : a.partial + (size_t)t.w * (size_t)a.D;
       sparse_task<L, VEC, true, UNROLL>(a.X, dst, a.col, __builtin_amdgcn_readfirstlane(t.y),
-                                        __builtin_amdgcn_readfirstlane(t.z), a.D, c0, cend, lane);
+                                        __builtin_amdgcn_readfirstlane(t.z), a.ldx, c0, cend, lane);
     } else {
       constexpr int R = 64 / L;
       const int g = lane / L;
@@ -213,9 +214,9 @@ __global__ __launch_bounds__(kThreads, MINW) void hybrid_plan_kernel(PlanArgs a)
         const int4 t = reinterpret_cast<const int4*>(a.plan + a.off_tasks)[tid];
         e0 = t.y;
         n = t.z;
-        dst = (t.w < 0) ? a.Z + (size_t)t.x * (size_t)a.D : a.partial + (size_t)t.w * (size_t)a.D;
+        dst = (t.w < 0) ? a.Z + (size_t)t.x * a.ldz : a.partial + (size_t)t.w * (size_t)a.D;
       }
-      sparse_task<L, VEC, false, UNROLL>(a.X, dst, a.col, e0, n, a.D, c0, cend, lane);
+      sparse_task<L, VEC, false, UNROLL>(a.X, dst, a.col, e0, n, a.ldx, c0, cend, lane);
     }
   } else {
     const int unit = ((int)blockIdx.x - a.sparse_wgs) * kWaves + wave;
@@ -225,9 +226,9 @@ __global__ __launch_bounds__(kThreads, MINW) void hybrid_plan_kernel(PlanArgs a)
     const int* U = a.plan + a.off_dense_pack + d.y;
     const unsigned long long* masks = reinterpret_cast<const unsigned long long*>(U + 4 * d.z);
     // floats per lane on the dense-tile path (a panel is 16*dvec columns): set by the launcher from D
-    if (VEC >= 4 && a.dense_vec == 4) dense_unit<(VEC >= 4 ? 4 : 1)>(a.X, a.Z, U, masks, d.z, d.x, panel, a.N, a.D, lane);
-    else if (VEC >= 2 && a.dense_vec == 2) dense_unit<(VEC >= 2 ? 2 : 1)>(a.X, a.Z, U, masks, d.z, d.x, panel, a.N, a.D, lane);
-    else dense_unit<1>(a.X, a.Z, U, masks, d.z, d.x, panel, a.N, a.D, lane);
+    if (VEC >= 4 && a.dense_vec == 4) dense_unit<(VEC >= 4 ? 4 : 1)>(a.X, a.Z, U, masks, d.z, d.x, panel, a.N, a.D, a.ldx, a.ldz, lane);
+    else if (VEC >= 2 && a.dense_vec == 2) dense_unit<(VEC >= 2 ? 2 : 1)>(a.X, a.Z, U, masks, d.z, d.x, panel, a.N, a.D, a.ldx, a.ldz, lane);
+    else dense_unit<1>(a.X, a.Z, U, masks, d.z, d.x, panel, a.N, a.D, a.ldx, a.ldz, lane);
   }
 }
 
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(kThreads) void fixup_kernel(PlanArgs a) {
       for (int u = 0; u < 4; ++u) acc += v[u];
     }
     for (; s < ns; ++s) acc += *reinterpret_cast<const vec_t*>(p + (size_t)s * (size_t)a.D);
-    *reinterpret_cast<vec_t*>(a.Z + (size_t)row * (size_t)a.D + c) = acc;
+    *reinterpret_cast<vec_t*>(a.Z + (size_t)row * a.ldz + c) = acc;
   }
 }
 
@@ -286,9 +287,9 @@ __global__ __launch_bounds__(kThreads) void hybrid_window_kernel(WindowArgs a) {
       if (r < r1) {
         e0 = a.rowptr[r];
         n = a.rowptr[r + 1] - e0;
-        dst = a.Z + (size_t)r * (size_t)a.D;
+        dst = a.Z + (size_t)r * a.ldz;
       }
-      sparse_task<L, VEC, false>(a.X, dst, a.col, e0, n, a.D, 0, a.D, lane);
+      sparse_task<L, VEC, false>(a.X, dst, a.col, e0, n, a.ldx, 0, a.D, lane);
     }
     return;
   }
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(kThreads) void hybrid_window_kernel(WindowArgs a) {
           const unsigned int mw = tv ? s_mask[t * 2 + (lane >> 5)] : 0u;
           av[u] = ((mw >> (lane & 31)) & 1u) ? 1.0f : 0.0f;
           x[u] = vzero<VEC>();
-          if (cok && idx >= 0) x[u] = *reinterpret_cast<const vec_t*>(a.X + (size_t)idx * (size_t)a.D + c);
+          if (cok && idx >= 0) x[u] = *reinterpret_cast<const vec_t*>(a.X + (size_t)idx * a.ldx + c);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(kThreads) void hybrid_window_kernel(WindowArgs a) {
           vec_t o;
 #pragma unroll
           for (int q = 0; q < VEC; ++q) vset(o, q, acc[q][r]);
-          *reinterpret_cast<vec_t*>(a.Z + (size_t)row * (size_t)a.D + c) = o;
+          *reinterpret_cast<vec_t*>(a.Z + (size_t)row * a.ldz + c) = o;
         }
       }
     }

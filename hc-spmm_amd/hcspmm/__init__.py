@@ -21,7 +21,7 @@ __all__ = [
     "forward_fixed64_fused", "forward_final_fused", "forward_final_fused_64", "forward_GIN_final_fused", "backward",
     "backward_fixed32", "backward_fixed32_fused", "backward_final_fused", "backward_fixed64",
     "backward_fixed64_fused", "backward_final_fused_64", "backward_GIN_final_fused", "loi_reorder",
-    "apply_permutation", "plan_header", "forward_rect", "wide_threshold", "build_plan", "set_default_rule", "RULE_INTENDED", "RULE_INTENDED_GUARD",
+    "apply_permutation", "plan_header", "forward_rect", "forward_into", "wide_threshold", "build_plan", "set_default_rule", "RULE_INTENDED", "RULE_INTENDED_GUARD",
     "RULE_AS_SHIPPED", "RULE_MI355X",
 ]
 
@@ -206,6 +206,38 @@ def forward_rect(X_full, row_pointers, column_index, blockPartition, edgeToColum
     indexing the rows of X_full (M x D, the all-gathered embedding matrix) -> [Z_local (n_local x D)]."""
     return [_spmm(X_full, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, hybrid_type, row_nzr,
                   col_nzr, rect=True)]
+
+
+def forward_into(X, Z, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, hybrid_type, row_nzr,
+                 col_nzr):
+    """Strided form: Z[:, :] = A @ X where X and Z may be column slices of wider matrices (unit inner
+    stride, any row stride) and X may have any number of rows (column ids index them).  Used by the
+    multi-GPU shard to multiply one gathered column panel at a time straight into its slice of Z."""
+    L = lib()
+    for t, n in ((row_pointers, "nodePointer"), (column_index, "edgeList"), (blockPartition, "blockPartition"),
+                 (edgeToColumn, "edgeToColumn"), (edgeToRow, "edgeToRow")):
+        _check_input(t, n)
+    for t, n in ((X, "input"), (Z, "output")):
+        if not t.is_cuda:
+            raise RuntimeError("%s must be a CUDA tensor" % n)
+        if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1 or t.stride(0) < t.size(1):
+            raise RuntimeError("%s must be a 2-D float32 view with unit inner stride" % n)
+    N, E, D = row_pointers.size(0) - 1, column_index.size(0), X.size(1)
+    if Z.size(0) != N or Z.size(1) != D:
+        raise RuntimeError("output must be [num_nodes, embedding_dim]")
+    h = plan_header(row_nzr, N, E) if (row_nzr is not None and row_nzr.is_cuda) else None
+    ws, ws_bytes = None, 0
+    if h is not None:
+        ws_bytes = int(L.hcspmm_workspace_bytes(ctypes.byref(h), D))
+        if ws_bytes:
+            ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=X.device)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(X.device).cuda_stream)
+    with torch.cuda.device(X.device):
+        check(L.hcspmm_forward_strided(_ptr(X), X.stride(0), _ptr(Z), Z.stride(0), _ptr(row_pointers),
+                                       _ptr(column_index), _ptr(blockPartition), _ptr(edgeToColumn), _ptr(edgeToRow),
+                                       _ptr(hybrid_type), _ptr(row_nzr) if h is not None else ctypes.c_void_p(0),
+                                       ctypes.byref(h) if h is not None else None, N, E, D, _ptr(ws), ws_bytes, stream))
+    return Z
 
 
 # The reference's dim-specialised variants compute the same product (hybrid_all.cpp:223-308);

@@ -43,6 +43,8 @@ SYMBOLS = {
     "hcspmm_workspace_bytes": (_sz, [_hp, _int]),
     "hcspmm_wide_threshold": (ctypes.c_int32, [_hp, _int]),
     "hcspmm_forward": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _hp, _i64, _i64, _int, _vp, _sz, _vp]),
+    "hcspmm_forward_strided": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _hp, _i64, _i64, _int, _vp, _sz,
+                                      _vp]),
     "hcspmm_forward_fused": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _hp,
                                     _i64, _i64, _int, _vp, _sz, _vp]),
     "hcspmm_loi_reorder": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, ctypes.POINTER(_i64)]),

@@ -70,37 +70,67 @@ class ShardedGraph:
 class ShardedSpMM:
     """Z_local = A[rows_p, :] @ all_gather(X_local).
 
-    local_spmm(X_full[P*pad_rows, D]) -> Z_local[n_local, D] is the local operator.  The gather and the
-    product run back to back on the caller's stream; cutting the feature columns into panels so that
-    the gather of panel k+1 overlaps the product of panel k is the planned next step (the gather is
-    the longer of the two on xGMI).
+    local_spmm(X_full[P*pad_rows, D]) -> Z_local[n_local, D] is the local operator.
+    With local_spmm_into(X_panel_full[P*pad_rows, w], Z_view[n_local, w]) and n_panels > 1 the feature
+    columns are cut into n_panels panels: every panel's all-gather is enqueued up front
+    (async_op=True, so RCCL runs them back to back on its own stream) and the product of panel k is
+    issued as soon as gather k has landed -- it overlaps gather k+1, which is the longer of the two on
+    xGMI.  Each gathered panel is a contiguous [P*pad_rows, w] matrix, which is
+    also the layout the gather kernel likes best (one cache line per row for w = 32), and each product
+    is written straight into its column slice of Z (strided operator, no concatenation).
     """
 
-    def __init__(self, graph, local_spmm, group=None):
+    def __init__(self, graph, local_spmm, group=None, local_spmm_into=None, n_panels=1):
         self.g = graph
         self.local_spmm = local_spmm
+        self.local_spmm_into = local_spmm_into
+        self.n_panels = n_panels if local_spmm_into is not None else 1
         self.group = group
+
+    def _pad(self, X_local):
+        g = self.g
+        if X_local.shape[0] == g.pad_rows:
+            return X_local
+        pad = torch.zeros((g.pad_rows, X_local.shape[1]), dtype=X_local.dtype, device=X_local.device)
+        pad[:g.n_local] = X_local
+        return pad
+
+    def _all_gather(self, full, part, async_op=False):
+        if part.is_cuda and dist.get_backend(self.group) != "nccl":
+            # rehearsal mode (e.g. several ranks sharing one GPU over gloo): stage through the host
+            host = torch.empty(full.shape, dtype=full.dtype)
+            dist.all_gather_into_tensor(host, part.cpu(), group=self.group)
+            full.copy_(host)
+            return None
+        return dist.all_gather_into_tensor(full, part, group=self.group, async_op=async_op)
 
     def gather(self, X_local):
         g = self.g
-        D = X_local.shape[1]
         if g.world_size == 1:
             return X_local
-        if X_local.shape[0] != g.pad_rows:
-            pad = torch.zeros((g.pad_rows, D), dtype=X_local.dtype, device=X_local.device)
-            pad[:g.n_local] = X_local
-            X_local = pad
-        full = torch.empty((g.world_size * g.pad_rows, D), dtype=X_local.dtype, device=X_local.device)
-        if X_local.is_cuda and dist.get_backend(self.group) != "nccl":
-            # rehearsal mode (e.g. several ranks sharing one GPU over gloo): stage through the host
-            host = torch.empty(full.shape, dtype=full.dtype)
-            dist.all_gather_into_tensor(host, X_local.contiguous().cpu(), group=self.group)
-            full.copy_(host)
-        else:
-            dist.all_gather_into_tensor(full, X_local.contiguous(), group=self.group)
+        X_local = self._pad(X_local).contiguous()
+        full = torch.empty((g.world_size * g.pad_rows, X_local.shape[1]), dtype=X_local.dtype, device=X_local.device)
+        self._all_gather(full, X_local)
         return full
 
     def forward(self, X_local):
-        return self.local_spmm(self.gather(X_local))
+        g = self.g
+        D = X_local.shape[1]
+        if g.world_size == 1 or self.n_panels <= 1 or D % self.n_panels != 0:
+            return self.local_spmm(self.gather(X_local))
+        w = D // self.n_panels
+        Xp = self._pad(X_local)
+        fulls, works = [], []
+        for p in range(self.n_panels):
+            part = Xp[:, p * w:(p + 1) * w].contiguous()
+            full = torch.empty((g.world_size * g.pad_rows, w), dtype=Xp.dtype, device=Xp.device)
+            works.append(self._all_gather(full, part, async_op=True))
+            fulls.append(full)
+        Z = torch.empty((g.n_local, D), dtype=Xp.dtype, device=Xp.device)
+        for p in range(self.n_panels):
+            if works[p] is not None:
+                works[p].wait()  # the current stream waits for gather p; gathers p+1.. keep running
+            self.local_spmm_into(fulls[p], Z[:, p * w:(p + 1) * w])
+        return Z
 
     __call__ = forward

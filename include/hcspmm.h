@@ -163,6 +163,16 @@ int hcspmm_forward(const float* X_d, float* Z_d, const int32_t* row_pointers_d, 
                    int64_t num_nodes, int64_t num_edges, int embedding_dim, void* workspace_d,
                    size_t workspace_bytes, void* stream);
 
+/* The same product on strided views: X rows are ldx elements apart, Z rows ldz (both >= embedding_dim),
+ * so a column panel of a wider matrix can be read / written in place (the multi-GPU shard gathers X
+ * panel by panel and writes each panel's product straight into its slice of Z). */
+int hcspmm_forward_strided(const float* X_d, int64_t ldx, float* Z_d, int64_t ldz, const int32_t* row_pointers_d,
+                           const int32_t* column_index_d, const int32_t* blockPartition_d,
+                           const int32_t* edgeToColumn_d, const int32_t* edgeToRow_d, const int32_t* hybrid_type_d,
+                           const int32_t* plan_d, const hcspmm_plan_header* plan_header_h, int64_t num_nodes,
+                           int64_t num_edges, int embedding_dim, void* workspace_d, size_t workspace_bytes,
+                           void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Fused aggregate + update: out2 = A * X (N x D), out = out2 * weights (N x H), weights row-major
  * D x H with row stride weights_ld_row and column stride weights_ld_col in elements (so a

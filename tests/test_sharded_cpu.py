@@ -47,6 +47,13 @@ def _worker(rank, world, port, seed, D, out_dir):
         Z_local = op(torch.from_numpy(X[g.r0:g.r1]))
         want = oracle.spmm_f32(rp, col, X)[g.r0:g.r1]
         ok = np.array_equal(Z_local.numpy(), want)
+
+        # pipelined form: column panels gathered asynchronously, each multiplied into its slice of Z
+        def local_spmm_into(X_panel_full, Z_view):
+            Z_view.copy_(torch.from_numpy(oracle.spmm_f32(g.row_pointers, g.column_index, X_panel_full.numpy())))
+
+        op2 = ShardedSpMM(g, local_spmm, local_spmm_into=local_spmm_into, n_panels=D // 4)
+        ok = ok and np.array_equal(op2(torch.from_numpy(X[g.r0:g.r1])).numpy(), want)
         # preprocess runs per shard on local windows with (remapped) global columns: host side only
         import hcspmm
         outs = hcspmm.preprocess(torch.from_numpy(g.column_index), torch.from_numpy(g.row_pointers), g.n_local,
@@ -113,7 +120,8 @@ def _gpu_worker(rank, world, port, out_dir):
         g = ShardedGraph(rp, col, partition_rows(rp, world), rank)
         rp_d, col_d = torch.from_numpy(g.row_pointers).to(dev), torch.from_numpy(g.column_index).to(dev)
         outs = hcspmm.preprocess(col_d, rp_d, g.n_local, len(g.column_index), (g.n_local + 15) // 16)
-        op = ShardedSpMM(g, lambda Xf: hcspmm.forward_rect(Xf, rp_d, col_d, *outs)[0])
+        op = ShardedSpMM(g, lambda Xf: hcspmm.forward_rect(Xf, rp_d, col_d, *outs)[0],
+                         local_spmm_into=lambda Xf, Zv: hcspmm.forward_into(Xf, Zv, rp_d, col_d, *outs), n_panels=2)
         Z = op(torch.from_numpy(X[g.r0:g.r1]).to(dev)).cpu().numpy()
         e0, e1 = rp[g.r0], rp[g.r1]
         ok, ratio = oracle.check_spmm(Z, (rp[g.r0:g.r1 + 1] - e0).astype(np.int32), col[e0:e1], X)

@@ -308,3 +308,24 @@ def test_offsets_beyond_2_to_31_elements(dev):
     assert torch.equal(Z[:, 0], want_t) and torch.equal(Z[:, D - 1], want_t) and torch.equal(Z[:, 100], want_t)
     del X, Z
     torch.cuda.empty_cache()
+
+
+def test_forward_into_strided_views(oracle_mod, dev):
+    """Strided operator: read a column panel of a wider X, write a column panel of a wider Z, in place."""
+    rp, col = graphs.planted_dense_graph(1500, seed=4)  # both sub-paths
+    g = Graph(rp, col, dev)
+    rng = np.random.default_rng(9)
+    Xw = rng.standard_normal((g.N, 160)).astype(np.float32)
+    Xd = _t(Xw, dev)
+    Zd = torch.full((g.N, 200), -7.0, device=dev)
+    for (x0, z0, w) in ((32, 64, 64), (0, 0, 32), (96, 136, 20)):
+        hcspmm.forward_into(Xd[:, x0:x0 + w], Zd[:, z0:z0 + w], *g.args())
+        ref = oracle_mod.spmm_f32(rp, col, np.ascontiguousarray(Xw[:, x0:x0 + w]))
+        got = Zd.cpu().numpy()
+        assert np.array_equal(got[:, z0:z0 + w], ref)
+        untouched = np.ones(200, bool)
+        untouched[z0:z0 + w] = False
+        Zd[:, z0:z0 + w] = -7.0
+        assert np.all(got[:, untouched] == -7.0)
+    with pytest.raises(RuntimeError, match="unit inner stride"):
+        hcspmm.forward_into(Xd.t()[:160, :g.N].t()[:, ::2], Zd[:, :80], *g.args())

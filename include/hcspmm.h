@@ -141,9 +141,8 @@ size_t hcspmm_workspace_bytes(const hcspmm_plan_header* header_h, int embedding_
 int32_t hcspmm_wide_threshold(const hcspmm_plan_header* header_h, int embedding_dim);
 
 /* ------------------------------------------------------------------------------------------
- * forward: Z = A * X.  Replaces the launchers spmm_forward_plus K.cu:410-455,
- * spmm_forward_plus_more :457-498, spmm_forward_plus_fixed32 :500-551, spmm_forward_plus_fixed64
- * :553-594 (bindings B.cpp:194-308; Python names forward / forward_more / forward_fixed32 /
+ * forward: Z = A * X.  Replaces the launchers spmm_forward_plus K.cu:410, spmm_forward_plus_more :457,
+ * spmm_forward_plus_fixed32 :500, spmm_forward_plus_fixed64 :553 (bindings B.cpp:194-308; Python names forward / forward_more / forward_fixed32 /
  * forward_fixed64 and the backward* aliases B.cpp:516-523) and the kernels
  * spmm_forward_cuda_kernel_arbi_warps_hybrid_{adaptive,adaptive_more,32,64} K.cu:919-1637.
  * One entry point serves every embedding_dim (the fixed32/fixed64 variants are the same math).
@@ -177,8 +176,8 @@ int hcspmm_forward_strided(const float* X_d, int64_t ldx, float* Z_d, int64_t ld
  * Fused aggregate + update: out2 = A * X (N x D), out = out2 * weights (N x H), weights row-major
  * D x H with row stride weights_ld_row and column stride weights_ld_col in elements (so a
  * transposed view, GNN_model.py:98,120, needs no copy).  Replaces spmm_forward_plus_fixed32_fused
- * K.cu:596-647, _fixed64_fused :649-697, _final_fused :699-755, _final_fused_64 :757-806,
- * _GIN_final_fused :808-863 (bindings B.cpp:310-498) and their kernels K.cu:1639-2770.
+ * K.cu:596, _fixed64_fused :651, _final_fused :701, _final_fused_64 :759, _GIN_final_fused :810
+ * (bindings B.cpp:310-498) and their kernels K.cu:1639-2770.
  * `out_d` may be a caller-owned buffer (forward_final_fused writes the caller's `output`).
  * ---------------------------------------------------------------------------------------- */
 int hcspmm_forward_fused(const float* X_d, float* out_d, float* out2_d, const float* weights_d,

@@ -85,24 +85,33 @@ __device__ __forceinline__ void sparse_task(const float* __restrict__ X, float* 
   for (int pbase = c0; pbase < cend; pbase += L * VEC) {  // feature columns [c0, cend) of the rows
     const int c = pbase + s * VEC;
     const bool cok = c < cend;
+    const int csafe = cok ? c : 0;
     vec_t acc = vzero<VEC>();
-    // the next chunk's indices are requested before the current chunk's rows, so a chunk costs one
-    // memory round trip instead of two
     int next = (pos < n) ? col[e0 + pos] : -1;
     for (int base = 0; base < nmax; base += STRIDE) {
       const int myidx = next;
-      next = (base + STRIDE + pos < n) ? col[e0 + base + STRIDE + pos] : -1;
+      const bool more = base + STRIDE + pos < n;
+      next = -1;
       const int cnt = min(L, nmax - base);  // longest lane group's share of this chunk
       for (int j = 0; j < cnt; j += U) {
+        // Branch-free batch: every lane issues all U loads (finished tasks and lanes beyond the
+        // embedding width re-read row 0 / column 0, an L1 hit, and discard it), so the batch is one
+        // basic block -- U broadcasts, U address computations, U loads back to back, one wait.
+        int idx[U];
         vec_t v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int idx = __shfl(myidx, gbase + j + u, 64);
-          v[u] = vzero<VEC>();
-          if (cok && idx >= 0) v[u] = *reinterpret_cast<const vec_t*>(X + (size_t)idx * ldx + c);
-        }
+        for (int u = 0; u < U; ++u) idx[u] = __shfl(myidx, gbase + j + u, 64);
+        // the next chunk's indices are requested here -- after this chunk's were consumed, ahead of
+        // its row loads -- so they arrive under those loads and a chunk costs one round trip, not two
+        if (j == 0 && more) next = col[e0 + base + STRIDE + pos];
 #pragma unroll
-        for (int u = 0; u < U; ++u) acc += v[u];
+        for (int u = 0; u < U; ++u)
+          v[u] = *reinterpret_cast<const vec_t*>(X + (size_t)max(idx[u], 0) * ldx + csafe);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (!(cok && idx[u] >= 0)) v[u] = vzero<VEC>();
+          acc += v[u];
+        }
       }
     }
     if (WIDE) {
@@ -134,6 +143,7 @@ __device__ __forceinline__ void dense_unit(const float* __restrict__ X, float* _
   const int kq = lane >> 4, j = lane & 15;
   const int c = panel * 16 * VEC + j * VEC;
   const bool cok = c < D;
+  const int csafe = cok ? c : 0;
   f32x4 acc[VEC];
 #pragma unroll
   for (int q = 0; q < VEC; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -143,19 +153,24 @@ __device__ __forceinline__ void dense_unit(const float* __restrict__ X, float* _
     const int steps = min(16, K4 - kb);
     constexpr int B = HCSPMM_DENSE_B * (4 / VEC);  // same bytes in flight per lane whatever the panel width
     for (int t0 = 0; t0 < steps; t0 += B) {
+      // Branch-free batch (see sparse_task): padded columns (U = -1) and steps past the end re-read
+      // row 0 and are zeroed by the select; their A tile is zero as well.
+      int idx[B];
       vec_t x[B];
       float a[B];
 #pragma unroll
       for (int u = 0; u < B; ++u) {
-        const int t = t0 + u;  // may run past `steps`: U pad (-1) and zero masks make it a no-op
-        const int idx = (t < steps) ? __shfl(myU, (4 * t + kq) & 63, 64) : -1;
-        const unsigned long long m = (t < steps) ? masks[kb + t] : 0ull;
-        a[u] = ((m >> lane) & 1ull) ? 1.0f : 0.0f;
-        x[u] = vzero<VEC>();
-        if (cok && idx >= 0) x[u] = *reinterpret_cast<const vec_t*>(X + (size_t)idx * ldx + c);
+        const int t = t0 + u;
+        idx[u] = __shfl(myU, (4 * t + kq) & 63, 64);
+        const unsigned long long m = masks[min(kb + t, K4 - 1)];  // wave-uniform address: scalar load
+        a[u] = (t < steps && ((m >> lane) & 1ull)) ? 1.0f : 0.0f;
+        if (t >= steps) idx[u] = -1;
       }
 #pragma unroll
+      for (int u = 0; u < B; ++u) x[u] = *reinterpret_cast<const vec_t*>(X + (size_t)max(idx[u], 0) * ldx + csafe);
+#pragma unroll
       for (int u = 0; u < B; ++u) {
+        if (!(cok && idx[u] >= 0)) x[u] = vzero<VEC>();
         if (t0 + u < steps) {  // wave-uniform: no MFMA issue slots for the padding of a short batch
 #pragma unroll
           for (int q = 0; q < VEC; ++q)

@@ -69,8 +69,7 @@ static int panel_choice(const hcspmm_plan_header* h, int D) {
 // power of two in [16, 256] not exceeding a quarter of that depth times 8: small (latency-bound)
 // launches hand every row longer than 16 entries to a whole wave, large (throughput-bound) ones
 // keep rows up to 256 entries on one lane group, in CSR order.
-static int wide_choice(const hcspmm_plan_header* h, int D, int* n_wide, int* latency_bound = nullptr,
-                       int* panel_cols = nullptr) {
+static int wide_choice(const hcspmm_plan_header* h, int D, int* n_wide, int* panel_cols = nullptr) {
   const int vec = (D % 4 == 0) ? 4 : (D % 2 == 0) ? 2 : 1;
   const int pw = panel_choice(h, D);
   if (panel_cols) *panel_cols = pw;
@@ -80,7 +79,6 @@ static int wide_choice(const hcspmm_plan_header* h, int D, int* n_wide, int* lat
   const int R = 64 / L;
   *n_wide = 0;
   const double work = passes * (double)h->nnz_sparse;
-  if (latency_bound) *latency_bound = work < 32.0 * 4.0 * 256.0 * 16.0;
   if (R == 1) return INT32_MAX;
   const double kResidentWaves = 256.0 * 16.0;
   const double t = 0.25 * work / ((double)R * kResidentWaves);
@@ -130,7 +128,7 @@ extern "C" int hcspmm_forward_strided(const float* X, int64_t ldx, float* Z, int
     a.n_dense = ph->n_dense;
     a.off_fixups = ph->off_fixups;
     a.n_split_rows = ph->n_split_rows;
-    wide_choice(ph, D, &a.n_wide, &a.latency_bound, &a.panel_cols);
+    wide_choice(ph, D, &a.n_wide, &a.panel_cols);
     a.sparse_wgs_pp = 0;
     a.dense_vec = 0;
     a.wide_wgs = 0;

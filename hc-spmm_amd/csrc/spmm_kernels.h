@@ -19,7 +19,6 @@ struct PlanArgs {
   int off_fixups, n_split_rows;
   int N, D;
   int n_wide;                          // the n_wide longest tasks are summed by whole waves
-  int latency_bound;                   // small launch: use the deep-MLP / low-occupancy build
   int panel_cols;                      // feature columns per sparse pass (D = one pass; 32 = panel-major)
   int sparse_wgs_pp, dense_vec;        // filled by the launcher
   int wide_wgs, sparse_wgs, n_panels;  // filled by the launcher

@@ -47,13 +47,13 @@ __device__ __forceinline__ void vset(float& v, int, float x) { v = x; }
 constexpr int kWaves = 4;            // waves per workgroup (256 threads)
 constexpr int kThreads = kWaves * 64;
 #ifndef HCSPMM_SPARSE_U
-#define HCSPMM_SPARSE_U 4  // row loads in flight per lane on the sparse-row path
+#define HCSPMM_SPARSE_U 8  // row loads in flight per lane on the sparse-row path
 #endif
 #ifndef HCSPMM_DENSE_B
-#define HCSPMM_DENSE_B 4   // k-steps (row loads in flight per lane) per batch on the dense-tile path
+#define HCSPMM_DENSE_B 8   // k-steps (row loads in flight per lane) per batch on the dense-tile path
 #endif
 #ifndef HCSPMM_MIN_WAVES_PER_SIMD
-#define HCSPMM_MIN_WAVES_PER_SIMD 8  // 64 registers per lane: 8 waves per SIMD (measured best: profiles/r01/ab_u_b_mw.log)
+#define HCSPMM_MIN_WAVES_PER_SIMD 4  // <= 128 registers per lane (measured best with U = B = 8: profiles/r01/ab_u_b_mw_v2.log)
 #endif
 
 // ------------------------------------------------------------------------------------------
@@ -197,8 +197,9 @@ __device__ __forceinline__ void dense_unit(const float* __restrict__ X, float* _
 // Planned hybrid kernel: ONE launch covers both sub-paths (as the reference's single launch
 // does, K.cu:960/1039) -- workgroups [0, wide_wgs) run wide sparse tasks, [wide_wgs, sparse_wgs) ordinary ones, the rest dense units.
 // ------------------------------------------------------------------------------------------
-// Two builds of the same kernel: <U = 4, 8 waves/SIMD> for throughput-bound launches (64 registers,
-// full occupancy) and <U = 8, 4 waves/SIMD> for latency-bound ones (few waves, deeper per-wave MLP).
+// UNROLL row loads in flight per lane, MINW waves per SIMD the register budget must allow.  With the
+// branch-free batches <8, 4> is best for throughput- and latency-bound launches alike
+// (profiles/r01/ab_u_b_mw_v2.log; before them <4, 8> won: profiles/r01/ab_u_b_mw.log).
 template <int L, int VEC, int UNROLL, int MINW>
 __global__ __launch_bounds__(kThreads, MINW) void hybrid_plan_kernel(PlanArgs a) {
   const int lane = threadIdx.x & 63;
@@ -395,11 +396,8 @@ static hipError_t launch_plan_LV(const PlanArgs& a, hipStream_t stream) {
   const long long grid = (long long)b.sparse_wgs + dense_wgs;
   if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
   if (grid > 0) {
-    if (a.latency_bound)
-      hipLaunchKernelGGL((hybrid_plan_kernel<L, VEC, 8, 4>), dim3((unsigned)grid), dim3(kThreads), 0, stream, b);
-    else
-      hipLaunchKernelGGL((hybrid_plan_kernel<L, VEC, HCSPMM_SPARSE_U, HCSPMM_MIN_WAVES_PER_SIMD>), dim3((unsigned)grid),
-                         dim3(kThreads), 0, stream, b);
+    hipLaunchKernelGGL((hybrid_plan_kernel<L, VEC, HCSPMM_SPARSE_U, HCSPMM_MIN_WAVES_PER_SIMD>), dim3((unsigned)grid),
+                       dim3(kThreads), 0, stream, b);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;

@@ -44,6 +44,9 @@ __device__ __forceinline__ void vset(f32x4& v, int i, float x) { v[i] = x; }
 __device__ __forceinline__ void vset(f32x2& v, int i, float x) { v[i] = x; }
 __device__ __forceinline__ void vset(float& v, int, float x) { v = x; }
 
+#ifndef HCSPMM_LDS_STAGE
+#define HCSPMM_LDS_STAGE 0  // 1: A/B build that stages the gathered rows through LDS (see sparse_task)
+#endif
 constexpr int kWaves = 4;            // waves per workgroup (256 threads)
 constexpr int kThreads = kWaves * 64;
 #ifndef HCSPMM_SPARSE_U
@@ -65,7 +68,7 @@ constexpr int kThreads = kWaves * 64;
 template <int L, int VEC, bool WIDE, int UMAX = HCSPMM_SPARSE_U>
 __device__ __forceinline__ void sparse_task(const float* __restrict__ X, float* __restrict__ dst,
                                             const int* __restrict__ col, int e0, int n, size_t ldx, int c0,
-                                            int cend, int lane) {
+                                            int cend, int lane, float* lds_stage = nullptr) {
   typedef typename VecT<VEC>::type vec_t;
   constexpr int U = (L < UMAX) ? L : UMAX;  // loads in flight per lane
   // WIDE: the whole wave owns ONE task (e0, n wave-uniform); per 64-entry super-chunk lane i holds
@@ -104,9 +107,26 @@ __device__ __forceinline__ void sparse_task(const float* __restrict__ X, float* 
         // the next chunk's indices are requested here -- after this chunk's were consumed, ahead of
         // its row loads -- so they arrive under those loads and a chunk costs one round trip, not two
         if (j == 0 && more) next = col[e0 + base + STRIDE + pos];
+#if HCSPMM_LDS_STAGE
+        // Experiment (north_star's "staged through LDS"): the batch's rows go HBM -> LDS by LDS-DMA
+        // (global_load_lds_dwordx4: per-lane source address, wave-linear destination), then each lane
+        // reads its 16 bytes back.  Same bytes, one extra LDS round trip; measured in
+        // profiles/r01/ab_lds_stage.log.  VEC == 4 only.
+        if (VEC == 4 && lds_stage != nullptr) {  // (the plan-free kernel passes no staging area)
+          float* stage = lds_stage + (threadIdx.x >> 6) * (U * 256);  // U x 1 KiB per wave
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-          v[u] = *reinterpret_cast<const vec_t*>(X + (size_t)max(idx[u], 0) * ldx + csafe);
+          for (int u = 0; u < U; ++u)
+            __builtin_amdgcn_global_load_lds(X + (size_t)max(idx[u], 0) * ldx + csafe, stage + u * 256, 16, 0, 0);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const vec_t*>(stage + u * 256 + lane * 4);
+        } else
+#endif
+        {
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            v[u] = *reinterpret_cast<const vec_t*>(X + (size_t)max(idx[u], 0) * ldx + csafe);
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           if (!(cok && idx[u] >= 0)) v[u] = vzero<VEC>();
@@ -202,6 +222,12 @@ __device__ __forceinline__ void dense_unit(const float* __restrict__ X, float* _
 // (profiles/r01/ab_u_b_mw_v2.log; before them <4, 8> won: profiles/r01/ab_u_b_mw.log).
 template <int L, int VEC, int UNROLL, int MINW>
 __global__ __launch_bounds__(kThreads, MINW) void hybrid_plan_kernel(PlanArgs a) {
+#if HCSPMM_LDS_STAGE
+  __shared__ __attribute__((aligned(16))) float s_stage[kWaves * UNROLL * 256];
+  float* lds_stage = s_stage;
+#else
+  float* lds_stage = nullptr;
+#endif
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if ((int)blockIdx.x < a.sparse_wgs) {
@@ -219,7 +245,7 @@ __global__ __launch_bounds__(kThreads, MINW) void hybrid_plan_kernel(PlanArgs a)
       const int4 t = reinterpret_cast<const int4*>(a.plan + a.off_tasks)[tid];
       float* dst = (t.w < 0) ? a.Z + (size_t)t.x * a.ldz : a.partial + (size_t)t.w * (size_t)a.D;
       sparse_task<L, VEC, true, UNROLL>(a.X, dst, a.col, __builtin_amdgcn_readfirstlane(t.y),
-                                        __builtin_amdgcn_readfirstlane(t.z), a.ldx, c0, cend, lane);
+                                        __builtin_amdgcn_readfirstlane(t.z), a.ldx, c0, cend, lane, lds_stage);
     } else {
       constexpr int R = 64 / L;
       const int g = lane / L;
@@ -232,7 +258,7 @@ __global__ __launch_bounds__(kThreads, MINW) void hybrid_plan_kernel(PlanArgs a)
         n = t.z;
         dst = (t.w < 0) ? a.Z + (size_t)t.x * a.ldz : a.partial + (size_t)t.w * (size_t)a.D;
       }
-      sparse_task<L, VEC, false, UNROLL>(a.X, dst, a.col, e0, n, a.ldx, c0, cend, lane);
+      sparse_task<L, VEC, false, UNROLL>(a.X, dst, a.col, e0, n, a.ldx, c0, cend, lane, lds_stage);
     }
   } else {
     const int unit = ((int)blockIdx.x - a.sparse_wgs) * kWaves + wave;

@@ -160,8 +160,18 @@ std::vector<torch::Tensor> preprocess(torch::Tensor edgeList_tensor, torch::Tens
                                       int edge_num, int block_num) {
   (void)edge_num;  // the reference's count is the raw line count (dataset.py:59); the tensor size is used
   auto dev = edgeList_tensor.device();
-  auto col = edgeList_tensor.to(torch::kCPU, torch::kInt).contiguous();
-  auto rp = nodePointer_tensor.to(torch::kCPU, torch::kInt).contiguous();
+  // large device arrays come back through a pinned buffer (a pageable D2H copy runs at ~1.4 GB/s)
+  auto to_host = [](const torch::Tensor& t) {
+    if (t.is_cuda() && t.scalar_type() == torch::kInt && t.is_contiguous() && t.numel() > (1 << 16)) {
+      auto host = torch::empty(t.sizes(), torch::TensorOptions().dtype(torch::kInt).pinned_memory(true));
+      host.copy_(t, /*non_blocking=*/true);
+      c10::hip::getCurrentHIPStream(t.device().index()).synchronize();
+      return host;
+    }
+    return t.to(torch::kCPU, torch::kInt).contiguous();
+  };
+  auto col = to_host(edgeList_tensor);
+  auto rp = to_host(nodePointer_tensor);
   const int64_t N = rp.numel() - 1, E = col.numel(), W = (N + HCSPMM_BLK_H - 1) / HCSPMM_BLK_H;
   TORCH_CHECK(num_nodes == N, "preprocess: num_nodes (", num_nodes, ") != row_pointers.size(0)-1 (", N, ")");
   TORCH_CHECK(block_num == W, "preprocess: num_row_windows (", block_num, ") != ceil(N/16) (", W, ")");

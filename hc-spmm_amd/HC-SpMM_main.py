@@ -37,6 +37,9 @@ def parse_args(argv=None):
     p.add_argument("--epochs", type=int, default=200, help="number of epoches")
     p.add_argument("--model", type=str, default="gcn", help="GNN model", choices=["gcn", "gin"])
     p.add_argument("--single_kernel", action="store_true", help="whether to profile a single SAG kernel")
+    # addition (the reference keeps this idea commented out, HC-SpMM_main.py:143-155): replay the whole
+    # training step from a HIP graph -- on small graphs an epoch is launch-bound, not kernel-bound
+    p.add_argument("--graph", action="store_true", help="capture the training step into a HIP graph and replay it")
     return p.parse_args(argv)
 
 
@@ -87,7 +90,7 @@ def main(argv=None):
 
     conv_cls = GCNConv if args.model == "gcn" else GINConv
     model = Net(conv_cls, dataset, graph, output, args.hidden, args.num_layers).to(device)
-    optimizer = torch.optim.Adam(model.parameters(), lr=0.01)
+    optimizer = torch.optim.Adam(model.parameters(), lr=0.01, capturable=args.graph)
 
     def train():
         model.train()
@@ -100,10 +103,27 @@ def main(argv=None):
     for _ in range(1, 10):  # dry run
         train()
     torch.cuda.synchronize()
+    step = train
+    if args.graph:
+        # the HCSPMM operators neither synchronise nor allocate outside torch's allocator, so the
+        # whole step (forward, backward, Adam) captures; static_loss is overwritten by every replay
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            optimizer.zero_grad(set_to_none=True)
+            with torch.cuda.graph(graph, stream=side):
+                static_loss = train()
+        torch.cuda.current_stream().wait_stream(side)
+
+        def step():
+            graph.replay()
+            return static_loss
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     loss = None
     for _ in tqdm(range(1, args.epochs + 1)):
-        loss = train()
+        loss = step()
     torch.cuda.synchronize()
     print("Train (ms/epoch):\t{:.3f}\tfinal loss {:.4f}".format((time.perf_counter() - t0) * 1e3 / max(args.epochs, 1),
                                                                  float(loss.detach()) if loss is not None else float("nan")))

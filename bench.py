@@ -36,6 +36,8 @@ WORKLOADS = {
     "reddit": (233000, 11600000, 128, "synthetic power-law, Reddit-scale (BASELINE config 3)"),
     "cora": (10000, 50000, 32, "synthetic power-law, Cora-scale (BASELINE config 2)"),
     "alldense": (1000000, 0, 128, "every window planted (16 rows sharing 20 columns): dense-tile path only, MFMA-utilisation probe"),
+    "products_share": (306250, 7750000, 256, "one GPU's row block of BASELINE config 4 (ogbn-products scale: 2.45 M nodes / 62 M entries over 8 GPUs); use with --virtual-world 8"),
+    "powerlaw16m_share": (2000000, 32000000, 128, "one GPU's row block of BASELINE config 5 (16 M nodes / 256 M entries over 8 GPUs); use with --virtual-world 8"),
     "dense": (2000000, 0, 128, "planted 16-row groups sharing <=24 columns, dense-tile heavy (BASELINE config 5 shape, per-GPU share)"),
 }
 
@@ -134,6 +136,9 @@ def main():
     ap.add_argument("--dim", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-plan", action="store_true", help="use the plan-free (reference-convention) kernel")
+    ap.add_argument("--virtual-world", type=int, default=1,
+                    help="one-GPU run of ONE rank's local product in a P-GPU job: the row block references columns of "
+                         "all P blocks and X holds all P*n rows (already 'gathered'); no communication is timed")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -166,7 +171,8 @@ def main():
 
     n_local, e_local, d_default, desc = WORKLOADS[args.workload]
     D = args.dim or d_default
-    rp, col = make_local_block(args.workload, n_local, e_local, world, rank)
+    vworld = max(1, args.virtual_world) if world == 1 else 1
+    rp, col = make_local_block(args.workload, n_local, e_local, world * vworld, rank)
     g = ShardedGraph.from_local_block(rp, col, n_local, world, rank)
     E = int(len(col))
     rp_d, col_d = torch.from_numpy(rp).to(dev), torch.from_numpy(col).to(dev)
@@ -178,7 +184,7 @@ def main():
     if args.no_plan:
         row_nzr = torch.zeros(1, dtype=torch.int32, device=dev)
     torch.manual_seed(1234 + rank)
-    X_local = torch.randn(n_local, D, device=dev)  # dataset.py:114 init_embedding
+    X_local = torch.randn(n_local * vworld, D, device=dev)  # dataset.py:114 init_embedding
 
     ev_pairs = []
 
@@ -246,8 +252,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo -- not a measurement)" if rehearsal else ""),
-            "config": {"workload": "%s: %s; %d nodes / %d stored entries per GPU, dim %d"
-                                   % (args.workload, desc, n_local, E, D),
+            "config": {"workload": "%s: %s; %d nodes / %d stored entries per GPU, dim %d%s"
+                                   % (args.workload, desc, n_local, E, D,
+                                      "" if vworld == 1 else "; ONE rank of a virtual %d-GPU job (X: %d rows resident)" % (vworld, n_local * vworld)),
                        "nodes_per_gpu": n_local, "entries_per_gpu": E, "dim": D, "parallelism": "row-block shard x%d + all-gather(X) in %d column panel(s)" % (world, n_gather_panels if world > 1 else 1),
                        "plan": (not args.no_plan), "sparse_tasks": header.n_tasks, "dense_windows": header.n_dense,
                        "split_rows": header.n_split_rows, "preprocess_ms": prep_ms},

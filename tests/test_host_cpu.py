@@ -246,3 +246,17 @@ def test_forward_requires_gpu_tensors():
     X = torch.zeros(64, 8)
     with pytest.raises(RuntimeError, match="input must be a CUDA tensor"):
         hcspmm.forward(X, _t(rp), _t(col), bp, e2c, e2r, ht, rn, cn)
+
+
+@pytest.mark.parametrize("name", ["powerlaw_777", "planted_640", "uniform_300"])
+def test_preprocess_frozen_fixture(oracle_mod, name):
+    """Oracle AND product against the committed integer fixture (tests/golden/preprocess_ints.npz)."""
+    g = np.load(os.path.join(GOLD, "preprocess_ints.npz"))
+    rp, col = g[name + "_row_pointers"], g[name + "_column_index"]
+    for rule in (0, 1, 2, 3):
+        o = oracle_mod.preprocess(rp, col, rule)
+        p = _pre(rp, col, rule)
+        for got in (o, [t.numpy() for t in p[:4]]):
+            assert np.array_equal(got[0], g["%s_rule%d_blockPartition" % (name, rule)])
+            assert np.array_equal(got[3], g["%s_rule%d_hybrid_type" % (name, rule)])
+            assert np.array_equal(got[1], g[name + "_edgeToColumn"]) and np.array_equal(got[2], g[name + "_edgeToRow"])

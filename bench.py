@@ -36,6 +36,9 @@ WORKLOADS = {
     "reddit": (233000, 11600000, 128, "synthetic power-law, Reddit-scale (BASELINE config 3)"),
     "cora": (10000, 50000, 32, "synthetic power-law, Cora-scale (BASELINE config 2)"),
     "alldense": (1000000, 0, 128, "every window planted (16 rows sharing 20 columns): dense-tile path only, MFMA-utilisation probe"),
+    "rd_like": (4859280, 10149830, 32, "synthetic power-law with the paper's RD size (Table II: 4.86 M nodes / 10.1 M entries), low degree"),
+    "tt_like": (3771081, 22011034, 32, "synthetic power-law with the paper's TT size (3.77 M nodes / 22.0 M entries)"),
+    "dp_like": (18268981, 172183984, 32, "synthetic power-law with the paper's DP size (18.3 M nodes / 172 M entries)"),
     "products_share": (306250, 7750000, 256, "one GPU's row block of BASELINE config 4 (ogbn-products scale: 2.45 M nodes / 62 M entries over 8 GPUs); use with --virtual-world 8"),
     "powerlaw16m_share": (2000000, 32000000, 128, "one GPU's row block of BASELINE config 5 (16 M nodes / 256 M entries over 8 GPUs); use with --virtual-world 8"),
     "dense": (2000000, 0, 128, "planted 16-row groups sharing <=24 columns, dense-tile heavy (BASELINE config 5 shape, per-GPU share)"),

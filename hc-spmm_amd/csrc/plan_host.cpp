@@ -4,8 +4,9 @@
 // lets hub rows serialise, hybrid_all_kernel.cu:435-438): the classified windows are turned into
 //   tasks   : one per sparse-path row (rows longer than split_threshold are cut into segments of
 //             segment_len entries whose partial sums a fix-up pass adds in order); tasks are
-//             sorted by descending length so that (a) the 64/L tasks sharing a wave have nearly
-//             equal trip counts and (b) the hardware dispatcher sees the heaviest work first;
+//             sorted by descending power-of-two length class (row order inside a class) so that
+//             (a) the 64/L tasks sharing a wave have trip counts within 2x, (b) the hardware
+//             dispatcher sees the heaviest work first, (c) neighbouring tasks touch neighbouring memory;
 //   dense   : per dense-path window, its ascending unique columns (K = 8*blockPartition, padded
 //             with -1) and, per 4-column k-step, the 64-bit lane mask of the 16x4 0/1 tile in
 //             v_mfma_f32_16x16x4_f32 A-operand order (lane = 16*(k%4) + row);
@@ -146,19 +147,29 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
       }
     }
   }
+  // Order: by descending power-of-two length class (0, 1, 2, 3-4, 5-8, 9-16, ...), rows ascending
+  // inside a class.  Classes keep the lane groups of a wave within 2x of each other and put the
+  // heavy work first; row order inside a class keeps the Z stores, the column-index reads and the
+  // task reads of neighbouring waves close together in memory (a full sort by length scatters them,
+  // which costs ~10 % on low-degree graphs where X and Z live in HBM, not in the Infinity Cache).
   int32_t len_gt[5] = {0, 0, 0, 0, 0};
   {
-    const int32_t maxlen = rp.split_threshold;
-    std::vector<int64_t> start((size_t)maxlen + 2, 0);
-    for (const Task& t : tasks) start[(size_t)(maxlen - t.len) + 1]++;  // bucket 0 = longest
+    auto cls = [](int32_t len) {  // 0 -> 0, 1 -> 1, 2 -> 2, 3..4 -> 3, 5..8 -> 4, 9..16 -> 5, 17..32 -> 6, ...
+      int c = 0;
+      while (len > 0) { ++c; len = (len == 1) ? 0 : (len + 1) / 2; }
+      return c;
+    };
+    const int n_cls = cls(rp.split_threshold) + 1;
+    std::vector<int64_t> start((size_t)n_cls + 1, 0);
+    for (const Task& t : tasks) start[(size_t)(n_cls - 1 - cls(t.len)) + 1]++;  // bucket 0 = longest class
     for (size_t i = 1; i < start.size(); ++i) start[i] += start[i - 1];
-    int32_t* out = plan + L.off_tasks;
-    for (int b = 0; b < 5; ++b) {  // prefix sizes: tasks longer than 16 << b
-      const int32_t thr = 16 << b;
-      len_gt[b] = thr >= maxlen ? 0 : (int32_t)start[(size_t)(maxlen - thr)];  // buckets [0, maxlen-thr) hold len > thr
+    for (int b = 0; b < 5; ++b) {  // prefix sizes: tasks longer than 16 << b  (class boundaries are powers of two)
+      const int c = cls((16 << b) + 1);  // first class whose members are all > 16 << b
+      len_gt[b] = c >= n_cls ? 0 : (int32_t)start[(size_t)(n_cls - c)];
     }
+    int32_t* out = plan + L.off_tasks;
     for (const Task& t : tasks) {
-      const int64_t p = start[(size_t)(maxlen - t.len)]++;
+      const int64_t p = start[(size_t)(n_cls - 1 - cls(t.len))]++;
       out[4 * p + 0] = t.row;
       out[4 * p + 1] = t.e0;
       out[4 * p + 2] = t.len;

@@ -59,6 +59,46 @@ constexpr int kThreads = kWaves * 64;
 #define HCSPMM_MIN_WAVES_PER_SIMD 4  // <= 128 registers per lane (measured best with U = B = 8: profiles/r01/ab_u_b_mw_v2.log)
 #endif
 
+// One branch-free batch of UB row gathers: every lane issues all UB loads (finished tasks and lanes
+// beyond the embedding width re-read row 0 / column 0, an L1 hit, and discard it), so the batch is one
+// basic block -- UB broadcasts, UB address computations, UB loads back to back, counted waits.
+template <int VEC, int UB>
+__device__ __forceinline__ void gather_batch(const float* __restrict__ X, size_t ldx, int csafe, bool cok, int myidx,
+                                             int src0, typename VecT<VEC>::type& acc, int lane, float* lds_stage,
+                                             const int* prefetch_from, int& prefetched) {
+  typedef typename VecT<VEC>::type vec_t;
+  int idx[UB];
+  vec_t v[UB];
+#pragma unroll
+  for (int u = 0; u < UB; ++u) idx[u] = __shfl(myidx, src0 + u, 64);
+  // the next chunk's indices are requested here -- after this chunk's were broadcast, ahead of its row
+  // loads -- so they arrive under those loads and a chunk costs one round trip, not two
+  if (prefetch_from != nullptr) prefetched = *prefetch_from;
+#if HCSPMM_LDS_STAGE
+  // Experiment (north_star's "staged through LDS"): the batch's rows go HBM -> LDS by LDS-DMA
+  // (global_load_lds_dwordx4: per-lane source address, wave-linear destination), then each lane reads
+  // its 16 bytes back.  Same bytes, one extra LDS round trip; measured in profiles/r01/ab_lds_stage.log.
+  if (VEC == 4 && lds_stage != nullptr) {  // (the plan-free kernel passes no staging area)
+    float* stage = lds_stage + (threadIdx.x >> 6) * (HCSPMM_SPARSE_U * 256);  // 1 KiB per load per wave
+#pragma unroll
+    for (int u = 0; u < UB; ++u)
+      __builtin_amdgcn_global_load_lds(X + (size_t)max(idx[u], 0) * ldx + csafe, stage + u * 256, 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < UB; ++u) v[u] = *reinterpret_cast<const vec_t*>(stage + u * 256 + lane * 4);
+  } else
+#endif
+  {
+#pragma unroll
+    for (int u = 0; u < UB; ++u) v[u] = *reinterpret_cast<const vec_t*>(X + (size_t)max(idx[u], 0) * ldx + csafe);
+  }
+#pragma unroll
+  for (int u = 0; u < UB; ++u) {
+    if (!(cok && idx[u] >= 0)) v[u] = vzero<VEC>();
+    acc += v[u];
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // Sparse-row task body: the L lanes [lane & ~(L-1), +L) own one task (row or row segment)
 // = CSR entries [e0, e0 + n); lane slot s covers columns pbase + s*VEC .. +VEC.  All control
@@ -96,42 +136,23 @@ __device__ __forceinline__ void sparse_task(const float* __restrict__ X, float* 
       const bool more = base + STRIDE + pos < n;
       next = -1;
       const int cnt = min(L, nmax - base);  // longest lane group's share of this chunk
-      for (int j = 0; j < cnt; j += U) {
-        // Branch-free batch: every lane issues all U loads (finished tasks and lanes beyond the
-        // embedding width re-read row 0 / column 0, an L1 hit, and discard it), so the batch is one
-        // basic block -- U broadcasts, U address computations, U loads back to back, one wait.
-        int idx[U];
-        vec_t v[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) idx[u] = __shfl(myidx, gbase + j + u, 64);
-        // the next chunk's indices are requested here -- after this chunk's were consumed, ahead of
-        // its row loads -- so they arrive under those loads and a chunk costs one round trip, not two
-        if (j == 0 && more) next = col[e0 + base + STRIDE + pos];
-#if HCSPMM_LDS_STAGE
-        // Experiment (north_star's "staged through LDS"): the batch's rows go HBM -> LDS by LDS-DMA
-        // (global_load_lds_dwordx4: per-lane source address, wave-linear destination), then each lane
-        // reads its 16 bytes back.  Same bytes, one extra LDS round trip; measured in
-        // profiles/r01/ab_lds_stage.log.  VEC == 4 only.
-        if (VEC == 4 && lds_stage != nullptr) {  // (the plan-free kernel passes no staging area)
-          float* stage = lds_stage + (threadIdx.x >> 6) * (U * 256);  // U x 1 KiB per wave
-#pragma unroll
-          for (int u = 0; u < U; ++u)
-            __builtin_amdgcn_global_load_lds(X + (size_t)max(idx[u], 0) * ldx + csafe, stage + u * 256, 16, 0, 0);
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-          for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const vec_t*>(stage + u * 256 + lane * 4);
-        } else
-#endif
-        {
-#pragma unroll
-          for (int u = 0; u < U; ++u)
-            v[u] = *reinterpret_cast<const vec_t*>(X + (size_t)max(idx[u], 0) * ldx + csafe);
+      const int* pf = more ? col + e0 + base + STRIDE + pos : nullptr;  // consumed by the chunk's first batch
+      for (int j = 0; j < cnt;) {
+        const int left = cnt - j;  // wave-uniform: short tasks (the bulk of a low-degree graph) get
+        if (left > U / 2) {        // short batches instead of a full one padded with dummy loads
+          gather_batch<VEC, U>(X, ldx, csafe, cok, myidx, gbase + j, acc, lane, lds_stage, pf, next);
+          j += U;
+        } else if (U >= 8 && left > U / 4) {
+          gather_batch<VEC, (U >= 8 ? U / 2 : 1)>(X, ldx, csafe, cok, myidx, gbase + j, acc, lane, lds_stage, pf, next);
+          j += U / 2;
+        } else if (U >= 4 && left > 1) {
+          gather_batch<VEC, (U >= 8 ? U / 4 : 2)>(X, ldx, csafe, cok, myidx, gbase + j, acc, lane, lds_stage, pf, next);
+          j += (U >= 8 ? U / 4 : 2);
+        } else {
+          gather_batch<VEC, 1>(X, ldx, csafe, cok, myidx, gbase + j, acc, lane, lds_stage, pf, next);
+          j += 1;
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          if (!(cok && idx[u] >= 0)) v[u] = vzero<VEC>();
-          acc += v[u];
-        }
+        pf = nullptr;
       }
     }
     if (WIDE) {

@@ -118,9 +118,13 @@ def test_plan_covers_every_entry_exactly_once(name, gen):
     ht = ht.numpy()
     cover = np.zeros(E, np.int32)
     rows_written = np.zeros(N, np.int32)
-    # sparse tasks: sorted by descending length, each <= split_threshold
+    # sparse tasks: sorted by descending power-of-two length class (0, 1, 2, 3-4, 5-8, ...), rows
+    # ascending inside a class; each <= split_threshold
     lens = tasks[:, 2]
-    assert np.all(np.diff(lens) <= 0) and (len(lens) == 0 or lens.max() <= h.split_threshold)
+    cls = np.where(lens > 0, np.ceil(np.log2(np.maximum(lens, 1))).astype(int) + 1, 0)
+    assert np.all(np.diff(cls) <= 0) and (len(lens) == 0 or lens.max() <= h.split_threshold)
+    for c in np.unique(cls):
+        assert np.all(np.diff(tasks[cls == c, 0]) >= 0)  # row order inside a class
     for row, e0, ln, slot in tasks:
         assert ht[row // 16] == 0 or rp[min((row // 16) * 16 + 16, N)] == rp[(row // 16) * 16]
         assert rp[row] <= e0 and e0 + ln <= rp[row + 1]

@@ -6,11 +6,14 @@
 // gathers and WMMA tf32 tiles staged through shared memory; this file is wave64 code built
 // around two facts of the machine (see /DESIGN.md):
 //
-//  * sparse-row path: the path is bound by how many gathered X-row bytes a CU keeps in flight,
-//    so rows become length-sorted *tasks* (host plan), L lanes of a wave own one task and walk
-//    its neighbours strictly in CSR order (bit-identical to a sequential fp32 sum), 64/L tasks
-//    share a wave, column indices are fetched coalesced once per L neighbours and broadcast
-//    through the LDS crossbar (ds_bpermute), and every lane issues 16-byte loads, U deep.
+//  * sparse-row path: the launch is bound by the gathered X-row bytes that miss the per-XCD L2, so
+//    (a) rows become *tasks* ordered by power-of-two length class (host plan); L lanes of a wave own
+//    one task and walk its neighbours strictly in CSR order (bit-identical to a sequential fp32
+//    sum), 64/L tasks share a wave; the longest tasks go to whole waves ("wide", shuffle-tree
+//    combine); (b) wide embeddings are processed panel-major, 32 columns (one cache line per row)
+//    at a time across the whole grid; (c) column indices are fetched coalesced once per L
+//    neighbours and broadcast through the LDS crossbar (ds_bpermute); every lane issues 16-byte
+//    loads in branch-free batches of 8.
 //  * dense-tile path: v_mfma_f32_16x16x4_f32 takes its B operand one fp32 per lane, so the
 //    gathered X rows go from HBM straight into MFMA operand registers with 16-byte loads (the
 //    four floats of a lane feed four MFMAs whose results re-assemble into a 16-byte store);

@@ -89,7 +89,11 @@ static int wide_choice(const hcspmm_plan_header* h, int D, int* n_wide, int* pan
 }
 
 extern "C" int32_t hcspmm_wide_threshold(const hcspmm_plan_header* h, int D) {
-  if (!h || D <= 0) return INT32_MAX;
+  if (D <= 0) return INT32_MAX;
+  if (!h) {  // plan-free kernel: fixed threshold (kPlanFreeWide in spmm_kernels.hip) unless a wave holds one lane group
+    const int vec = (D % 4 == 0) ? 4 : (D % 2 == 0) ? 2 : 1;
+    return (D + vec - 1) / vec > 32 ? INT32_MAX : 64;
+  }
   int n_wide = 0;
   return wide_choice(h, D, &n_wide);
 }

@@ -333,6 +333,7 @@ __global__ __launch_bounds__(kThreads) void fixup_kernel(PlanArgs a) {
 // kChunkK condensed columns, so any blockPartition is handled.
 // ------------------------------------------------------------------------------------------
 constexpr int kChunkK = 512;  // condensed columns per LDS pass (128 k-steps)
+constexpr int kPlanFreeWide = 64;  // plan-free kernel: rows longer than this are summed by a whole wave
 
 template <int L, int VEC>
 __global__ __launch_bounds__(kThreads) void hybrid_window_kernel(WindowArgs a) {
@@ -340,12 +341,14 @@ __global__ __launch_bounds__(kThreads) void hybrid_window_kernel(WindowArgs a) {
   __shared__ unsigned int s_mask[kChunkK / 4 * 2];  // 64-bit lane masks as two 32-bit halves
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nthreads = (int)blockDim.x, nwaves = nthreads >> 6;  // 1-4 waves: sized to the window's work
   const int w = blockIdx.x;
   const int r0 = w * 16, r1 = min(r0 + 16, a.N);
   if (a.hybrid_type[w] == 0) {
     constexpr int R = 64 / L;
-    constexpr int G = R * kWaves;  // lane groups per workgroup
+    const int G = R * nwaves;  // lane groups per workgroup
     const int gi = wave * R + lane / L;
+    // rows up to kPlanFreeWide entries: one lane group each, strict CSR order
     for (int rb = r0; rb < r1; rb += G) {  // uniform
       const int r = rb + gi;
       int e0 = 0, n = 0;
@@ -354,8 +357,26 @@ __global__ __launch_bounds__(kThreads) void hybrid_window_kernel(WindowArgs a) {
         e0 = a.rowptr[r];
         n = a.rowptr[r + 1] - e0;
         dst = a.Z + (size_t)r * a.ldz;
+        if (R > 1 && n > kPlanFreeWide) {  // left to the whole-wave pass below
+          n = 0;
+          dst = nullptr;
+        }
       }
       sparse_task<L, VEC, false>(a.X, dst, a.col, e0, n, a.ldx, 0, a.D, lane);
+    }
+    // longer rows: whole waves (all 64/L lane groups on one row, shuffle-tree combine), dealt
+    // round-robin over the workgroup's waves -- a hub row no longer crawls on one lane group
+    if (R > 1) {
+      int k = 0;
+      for (int r = r0; r < r1; ++r) {  // uniform scan of the window's rows
+        const int e0 = a.rowptr[r];
+        const int n = a.rowptr[r + 1] - e0;
+        if (n > kPlanFreeWide) {
+          if (k % nwaves == wave)
+            sparse_task<L, VEC, true>(a.X, a.Z + (size_t)r * a.ldz, a.col, e0, n, a.ldx, 0, a.D, lane);
+          ++k;
+        }
+      }
     }
     return;
   }
@@ -364,7 +385,7 @@ __global__ __launch_bounds__(kThreads) void hybrid_window_kernel(WindowArgs a) {
   const int K = a.blockPartition[w] * 8;
   const int n_panels = (a.D + 16 * VEC - 1) / (16 * VEC);
   const int kq = lane >> 4, j = lane & 15;
-  for (int pb = 0; pb < n_panels; pb += kWaves) {  // uniform over the workgroup
+  for (int pb = 0; pb < n_panels; pb += nwaves) {  // uniform over the workgroup
     const int panel = pb + wave;
     const int c = panel * 16 * VEC + j * VEC;
     const bool cok = panel < n_panels && c < a.D;
@@ -374,10 +395,10 @@ __global__ __launch_bounds__(kThreads) void hybrid_window_kernel(WindowArgs a) {
     for (int k0 = 0; k0 < K; k0 += kChunkK) {  // uniform
       const int kc = min(kChunkK, K - k0);
       __syncthreads();
-      for (int i = threadIdx.x; i < kChunkK; i += kThreads) s_U[i] = -1;
-      for (int i = threadIdx.x; i < kChunkK / 2; i += kThreads) s_mask[i] = 0u;
+      for (int i = threadIdx.x; i < kChunkK; i += nthreads) s_U[i] = -1;
+      for (int i = threadIdx.x; i < kChunkK / 2; i += nthreads) s_mask[i] = 0u;
       __syncthreads();
-      for (int e = lo + (int)threadIdx.x; e < hi; e += kThreads) {
+      for (int e = lo + (int)threadIdx.x; e < hi; e += nthreads) {
         const int cc = a.edgeToColumn[e] - k0;
         if (cc >= 0 && cc < kc) {
           const int rl = a.edgeToRow[e] - r0;
@@ -462,7 +483,13 @@ static hipError_t launch_plan_LV(const PlanArgs& a, hipStream_t stream) {
 template <int L, int VEC>
 static hipError_t launch_window_LV(const WindowArgs& a, hipStream_t stream) {
   const int W = (a.N + 15) / 16;
-  if (W > 0) hipLaunchKernelGGL((hybrid_window_kernel<L, VEC>), dim3(W), dim3(kThreads), 0, stream, a);
+  // 16 rows x L lanes of sparse work, D/(16*VEC) dense panels: narrow embeddings get narrower workgroups
+  // (a 256-thread workgroup per window is dispatch-bound when each window holds a handful of entries)
+  const int n_panels = (a.D + 16 * VEC - 1) / (16 * VEC);
+  int waves = (16 * L + 63) / 64;
+  if (n_panels > waves) waves = n_panels;
+  if (waves > kWaves) waves = kWaves;
+  if (W > 0) hipLaunchKernelGGL((hybrid_window_kernel<L, VEC>), dim3(W), dim3(waves * 64), 0, stream, a);
   return hipGetLastError();
 }
 

@@ -73,9 +73,7 @@ def wide_threshold(row_nzr, embedding_dim):
     """Rows of the sparse path with more entries than this are summed by a whole wave (shuffle-tree
     combine) instead of one lane group in CSR order; see hcspmm_wide_threshold in include/hcspmm.h."""
     h = plan_header(row_nzr)
-    if h is None:
-        return 2 ** 31 - 1
-    return int(lib().hcspmm_wide_threshold(ctypes.byref(h), int(embedding_dim)))
+    return int(lib().hcspmm_wide_threshold(ctypes.byref(h) if h is not None else None, int(embedding_dim)))
 
 
 def _ptr(t):

@@ -137,7 +137,8 @@ size_t hcspmm_workspace_bytes(const hcspmm_plan_header* header_h, int embedding_
  * sequential CSR order); rows at or below it are summed strictly in CSR order by one lane group,
  * bit-identical to the reference's sparse-row loop (K.cu:1377-1380).  Small graphs get a small
  * threshold (latency-bound: the longest row's dependent-load chain is the kernel time), large
- * graphs a large one (throughput-bound).  Returns INT32_MAX when no task is wide. */
+ * graphs a large one (throughput-bound).  Returns INT32_MAX when no task is wide.  header_h == NULL
+ * asks about the plan-free kernel (fixed threshold of 64 entries). */
 int32_t hcspmm_wide_threshold(const hcspmm_plan_header* header_h, int embedding_dim);
 
 /* ------------------------------------------------------------------------------------------

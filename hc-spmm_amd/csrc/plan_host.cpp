@@ -151,7 +151,8 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
   // inside a class.  Classes keep the lane groups of a wave within 2x of each other and put the
   // heavy work first; row order inside a class keeps the Z stores, the column-index reads and the
   // task reads of neighbouring waves close together in memory (a full sort by length scatters them,
-  // which costs ~10 % on low-degree graphs where X and Z live in HBM, not in the Infinity Cache).
+  // which costs a few % on low-degree graphs where X and Z live in HBM, not in the Infinity Cache;
+  // merging all rows <= 16 entries into ONE row-ordered class is worse, profiles/r01/ab_merge_short.log).
   int32_t len_gt[5] = {0, 0, 0, 0, 0};
   {
     auto cls = [](int32_t len) {  // 0 -> 0, 1 -> 1, 2 -> 2, 3..4 -> 3, 5..8 -> 4, 9..16 -> 5, 17..32 -> 6, ...

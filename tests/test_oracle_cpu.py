@@ -158,3 +158,25 @@ def test_golden_csr_fixture_is_scipy_tocsr_semantics():
         rp, col = g[name + "_row_pointers"], g[name + "_column_index"]
         for r in range(n):
             assert np.all(np.diff(col[rp[r]:rp[r + 1]]) > 0)
+
+
+def test_config1_example_dataset_against_torch_sparse_mm(oracle_mod):
+    """BASELINE config 1 plumbing on CPU: the `example` dataset (hc-spmm_amd/Dataset/example.txt, dim 16)
+    through our loader, A*X from the oracle vs torch.sparse.mm (CSR and COO)."""
+    import sys
+    import torch
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hc-spmm_amd")
+    if pkg not in sys.path:
+        sys.path.insert(0, pkg)
+    from dataset import HCSPMM_dataset
+    ds = HCSPMM_dataset(os.path.join(pkg, "Dataset", "example.txt"), 16, 22, device="cpu", seed=0)
+    rp, col = ds.row_pointers.numpy(), ds.column_index.numpy()
+    X = ds.x.numpy()
+    A = torch.sparse_csr_tensor(ds.row_pointers.long(), ds.column_index.long(), torch.ones(len(col)),
+                                size=(ds.num_nodes, ds.num_nodes))
+    want = torch.sparse.mm(A, ds.x).numpy()
+    got = oracle_mod.spmm_f32(rp, col, X)
+    ok, ratio = oracle_mod.check_spmm(want, rp, col, X)
+    assert ok, ratio  # torch's own result is within the bar of the fp64 product
+    assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
+    assert np.abs(torch.sparse.mm(A.to_sparse_coo(), ds.x).numpy() - want).max() <= 1e-5 * np.abs(want).max()

@@ -164,6 +164,9 @@ def _check_input(t, name):
         raise RuntimeError("%s must be contiguous" % name)
 
 
+_VALIDATE = os.environ.get("HCSPMM_VALIDATE", "0") == "1"
+
+
 def _graph_args(X, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, hybrid_type, row_nzr,
                 rect=False):
     for t, n in ((X, "input"), (row_pointers, "nodePointer"), (column_index, "edgeList"),
@@ -176,6 +179,10 @@ def _graph_args(X, row_pointers, column_index, blockPartition, edgeToColumn, edg
     D = X.size(1)
     if X.size(0) != N and not rect:
         raise RuntimeError("input has %d rows but the graph has %d nodes" % (X.size(0), N))
+    if _VALIDATE and E > 0:  # HCSPMM_VALIDATE=1: a column id outside X would be an out-of-bounds gather on the GPU
+        lo, hi = int(column_index.min()), int(column_index.max())
+        if lo < 0 or hi >= X.size(0):
+            raise RuntimeError("column_index out of range [0, %d): min %d max %d" % (X.size(0), lo, hi))
     h = plan_header(row_nzr, N, E) if (row_nzr is not None and row_nzr.is_cuda) else None
     return N, E, D, h
 

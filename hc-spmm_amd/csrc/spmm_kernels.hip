@@ -50,6 +50,17 @@ __device__ __forceinline__ void vset(float& v, int, float x) { v = x; }
 #ifndef HCSPMM_LDS_STAGE
 #define HCSPMM_LDS_STAGE 0  // 1: A/B build that stages the gathered rows through LDS (see sparse_task)
 #endif
+#ifndef HCSPMM_NT_STORE
+#define HCSPMM_NT_STORE 1  // Z rows are written once and not re-read by this launch: non-temporal stores (0-5 %, profiles/r01/ab_nt_store.log)
+#endif
+template <typename V>
+__device__ __forceinline__ void store_out(V* p, const V& v) {
+#if HCSPMM_NT_STORE
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
 constexpr int kWaves = 4;            // waves per workgroup (256 threads)
 constexpr int kThreads = kWaves * 64;
 #ifndef HCSPMM_SPARSE_U
@@ -164,9 +175,9 @@ __device__ __forceinline__ void sparse_task(const float* __restrict__ X, float* 
 #pragma unroll
         for (int q = 0; q < VEC; ++q) vset(acc, q, vget(acc, q) + __shfl_xor(vget(acc, q), off, 64));
       }
-      if (cok && dst != nullptr && lane < L) *reinterpret_cast<vec_t*>(dst + c) = acc;
+      if (cok && dst != nullptr && lane < L) store_out(reinterpret_cast<vec_t*>(dst + c), acc);
     } else {
-      if (cok && dst != nullptr) *reinterpret_cast<vec_t*>(dst + c) = acc;
+      if (cok && dst != nullptr) store_out(reinterpret_cast<vec_t*>(dst + c), acc);
     }
   }
 }
@@ -231,7 +242,7 @@ __device__ __forceinline__ void dense_unit(const float* __restrict__ X, float* _
         vec_t o;
 #pragma unroll
         for (int q = 0; q < VEC; ++q) vset(o, q, acc[q][r]);
-        *reinterpret_cast<vec_t*>(Z + (size_t)row * ldz + c) = o;
+        store_out(reinterpret_cast<vec_t*>(Z + (size_t)row * ldz + c), o);
       }
     }
   }
@@ -320,7 +331,7 @@ __global__ __launch_bounds__(kThreads) void fixup_kernel(PlanArgs a) {
       for (int u = 0; u < 4; ++u) acc += v[u];
     }
     for (; s < ns; ++s) acc += *reinterpret_cast<const vec_t*>(p + (size_t)s * (size_t)a.D);
-    *reinterpret_cast<vec_t*>(a.Z + (size_t)row * a.ldz + c) = acc;
+    store_out(reinterpret_cast<vec_t*>(a.Z + (size_t)row * a.ldz + c), acc);
   }
 }
 

@@ -9,12 +9,7 @@
 // per-group N-bit bitmap (LOI.cpp:695, O(N^2/16) overall) and its re-sorted column vector
 // (LOI.cpp:71), and there is no static 18 269 000-entry table (LOI.cpp:96).
 #include <algorithm>
-#include <atomic>
-#include <condition_variable>
 #include <cstdint>
-#include <cstdlib>
-#include <mutex>
-#include <thread>
 #include <vector>
 
 #include "hcspmm.h"
@@ -36,115 +31,6 @@ extern "C" int hcspmm_loi_reorder_variant(const int32_t* rowptr, const int32_t* 
 }
 
 namespace {
-
-// Candidate pricing in parallel.  A pick is  argmax over the candidate list (in discovery order) of a
-// float profit, first-seen winning ties; hub columns make that list tens of thousands long and every
-// one of a group's 15 picks rescans it.  The scan is split into contiguous chunks, each worker returns
-// its chunk's (best profit, first index reaching it), and the chunks are combined in order with a
-// strict '>' -- exactly the sequential result.  Workers spin on a generation counter (a scan lasts
-// microseconds; futex wake-ups would cost more than the scan).
-class ScanPool {
- public:
-  struct Job {
-    const int32_t* cand = nullptr;
-    const uint8_t* visit = nullptr;
-    const int32_t* shared = nullptr;
-    const int32_t* rowptr = nullptr;
-    int64_t n = 0;
-    int32_t ones = 0, ncols = 0;
-    bool first = false;
-  };
-  struct Best {
-    float profit = 0.0f;
-    int64_t pos = -1;
-  };
-
-  explicit ScanPool(int threads) : T_(threads < 1 ? 1 : threads), best_((size_t)T_) {
-    for (int t = 1; t < T_; ++t) workers_.emplace_back([this, t] { work(t); });
-  }
-  ~ScanPool() {
-    stop_.store(true, std::memory_order_release);
-    gen_.fetch_add(1, std::memory_order_acq_rel);
-    set_active(true);
-    for (auto& w : workers_) w.join();
-  }
-  // Workers spin only while a group with a long candidate list is being grown; otherwise they are
-  // parked on a condition variable (most groups of most graphs never need them).
-  void set_active(bool on) {
-    if (T_ == 1 || active_.load(std::memory_order_acquire) == on) return;
-    {
-      std::lock_guard<std::mutex> lk(mu_);
-      active_.store(on, std::memory_order_release);
-    }
-    if (on) cv_.notify_all();
-  }
-  int threads() const { return T_; }
-
-  static Best scan(const Job& j, int64_t lo, int64_t hi) {
-    Best b;
-    for (int64_t i = lo; i < hi; ++i) {
-      const int32_t v = j.cand[i];
-      if (j.visit[v]) continue;
-      const int32_t d = j.rowptr[v + 1] - j.rowptr[v];
-      const int32_t o = j.ones + d;
-      const int32_t rws = j.first ? (o - j.shared[v]) : (j.ncols + d - j.shared[v]);
-      const float profit = (float)o / (float)rws;
-      if (profit > b.profit) {
-        b.profit = profit;
-        b.pos = i;
-      }
-    }
-    return b;
-  }
-
-  Best run(const Job& j) {
-    if (T_ == 1 || j.n < 8192) return scan(j, 0, j.n);
-    set_active(true);
-    job_ = j;
-    done_.store(0, std::memory_order_relaxed);
-    gen_.fetch_add(1, std::memory_order_acq_rel);  // publish the job
-    best_[0] = scan(j, 0, chunk_end(0, j.n));
-    while (done_.load(std::memory_order_acquire) != T_ - 1) {
-    }
-    Best b = best_[0];
-    for (int t = 1; t < T_; ++t)
-      if (best_[(size_t)t].profit > b.profit) b = best_[(size_t)t];  // chunks in order + strict '>': first-seen wins
-    return b;
-  }
-
- private:
-  int64_t chunk_end(int t, int64_t n) const { return n * (t + 1) / T_; }
-  void work(int t) {
-    uint64_t seen = 0;
-    for (;;) {
-      uint64_t g;
-      while ((g = gen_.load(std::memory_order_acquire)) == seen) {
-        if (!active_.load(std::memory_order_acquire)) {
-          std::unique_lock<std::mutex> lk(mu_);
-          cv_.wait(lk, [this] { return active_.load(std::memory_order_acquire); });
-        } else {
-          __builtin_ia32_pause();
-        }
-      }
-      seen = g;
-      if (stop_.load(std::memory_order_acquire)) return;
-      const Job j = job_;
-      best_[(size_t)t] = scan(j, chunk_end(t - 1, j.n), chunk_end(t, j.n));
-      done_.fetch_add(1, std::memory_order_release);
-    }
-  }
-  const int T_;
-  std::vector<Best> best_;
-  std::vector<std::thread> workers_;
-  Job job_;
-  std::atomic<uint64_t> gen_{0};
-  std::atomic<int> done_{0};
-  std::atomic<bool> stop_{false};
-  std::atomic<bool> active_{false};
-  std::mutex mu_;
-  std::condition_variable cv_;
-};
-
 int loi_reorder_impl(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, int variant, int32_t* perm_out,
                      int32_t* group_sizes_out, int64_t* n_groups_out) {
   if (N < 0 || E < 0 || !rowptr || (N > 0 && !perm_out) || (E > 0 && !col)) return HCSPMM_EINVAL;
@@ -178,11 +64,6 @@ int loi_reorder_impl(const int32_t* rowptr, const int32_t* col, int64_t N, int64
   std::vector<std::vector<int32_t>> groups;
   auto deg = [&](int32_t v) { return rowptr[v + 1] - rowptr[v]; };
 
-  // HCSPMM_LOI_THREADS overrides (1 = the plain sequential scan)
-  const char* env_threads = getenv("HCSPMM_LOI_THREADS");
-  const int want_threads = env_threads ? atoi(env_threads)
-                                       : (E > (1 << 20) ? std::min(32, (int)std::thread::hardware_concurrency()) : 1);
-  ScanPool pool(want_threads);
   int32_t gid = 0;
   int64_t seed_scan = 0;
   for (;;) {
@@ -217,19 +98,20 @@ int loi_reorder_impl(const int32_t* rowptr, const int32_t* col, int64_t N, int64
           }
         }
       }
-      // first pick: the reference prices against the seed's own entry count (LOI.cpp:726-727), later
-      // picks against the group's distinct-column count (LOI.cpp:775-776)
-      ScanPool::Job job;
-      job.cand = cand.data();
-      job.visit = visit.data();
-      job.shared = shared.data();
-      job.rowptr = rowptr;
-      job.n = (int64_t)cand.size();
-      job.ones = ones;
-      job.ncols = ncols;
-      job.first = first;
-      const ScanPool::Best b = pool.run(job);
-      const int32_t best = b.pos < 0 ? -1 : cand[(size_t)b.pos];
+      int32_t best = -1;
+      float best_profit = 0.0f;
+      for (int32_t v : cand) {
+        if (visit[(size_t)v]) continue;
+        const int32_t o = ones + deg(v);
+        // first pick: the reference prices against the seed's own entry count (LOI.cpp:726-727),
+        // later picks against the group's distinct-column count (LOI.cpp:775-776)
+        const int32_t rws = first ? (o - shared[(size_t)v]) : (ncols + deg(v) - shared[(size_t)v]);
+        const float profit = (float)o / (float)rws;
+        if (profit > best_profit) {
+          best = v;
+          best_profit = profit;
+        }
+      }
       if (best < 0) break;
       grp.push_back(best);
       visit[(size_t)best] = 1;
@@ -246,7 +128,6 @@ int loi_reorder_impl(const int32_t* rowptr, const int32_t* col, int64_t N, int64
       ones += deg(best);
       first = false;
     }
-    pool.set_active(false);
     for (int32_t v : cand) shared[(size_t)v] = 0;
     groups.push_back(std::move(grp));
     ++gid;

@@ -221,21 +221,6 @@ def test_loi_reorder_matches_oracle_on_larger_graph():
     assert sizes.tolist() == [len(x) for x in groups]
 
 
-def test_loi_parallel_candidate_scan_is_exact(monkeypatch):
-    """Hub-heavy graph: candidate lists of tens of thousands of rows, priced by the worker pool; the
-    result must be the sequential one bit for bit (first-seen tie-breaking included)."""
-    rp, col = graphs.powerlaw_graph(40000, 1300000, seed=31, exponent=1.9, max_degree_frac=0.6)
-    assert np.diff(rp).max() > 9000  # candidate lists beyond the 8192-row parallel threshold
-    monkeypatch.setenv("HCSPMM_LOI_THREADS", "1")
-    perm1, sizes1 = hcspmm.loi_reorder(_t(rp), _t(col))
-    monkeypatch.setenv("HCSPMM_LOI_THREADS", "5")
-    perm5, sizes5 = hcspmm.loi_reorder(_t(rp), _t(col))
-    monkeypatch.delenv("HCSPMM_LOI_THREADS")
-    permd, sizesd = hcspmm.loi_reorder(_t(rp), _t(col))
-    assert torch.equal(perm1, perm5) and torch.equal(sizes1, sizes5)
-    assert torch.equal(perm1, permd) and torch.equal(sizes1, sizesd)
-
-
 def test_apply_permutation_is_a_graph_isomorphism():
     import scipy.sparse as sp
     rp, col = graphs.powerlaw_graph(700, 5000, seed=6)

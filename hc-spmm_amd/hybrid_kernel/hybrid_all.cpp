@@ -259,4 +259,39 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     g_params.segment_len = segment_len;
   }, "rows longer than split_threshold are cut into segments of segment_len entries (0 = defaults)");
   m.def("abi_version", []() { return hcspmm_abi_version(); });
+  // LOI layout reorder on the host (the reference ships it as a separate file-to-file program, LOI.cpp)
+  m.def("loi_reorder", [](torch::Tensor row_pointers, torch::Tensor column_index, int variant) {
+    auto rp = row_pointers.to(torch::kCPU, torch::kInt).contiguous();
+    auto col = column_index.to(torch::kCPU, torch::kInt).contiguous();
+    const int64_t N = rp.numel() - 1, E = col.numel();
+    auto perm = torch::empty({N}, torch::kInt), sizes = torch::empty({std::max<int64_t>(N, 1)}, torch::kInt);
+    int64_t ng = 0;
+    check_rc(hcspmm_loi_reorder_variant(rp.data_ptr<int>(), iptr(col), N, E, variant, mptr(perm), sizes.data_ptr<int>(), &ng),
+             "loi_reorder");
+    return std::vector<torch::Tensor>{perm, sizes.slice(0, 0, ng).clone()};
+  }, "-> [perm (old vertex id at each new position), group sizes]; variant 0 = reorder_plus_new_direct, 1 = reorder_plus_new",
+        pybind11::arg("row_pointers"), pybind11::arg("column_index"), pybind11::arg("variant") = 0);
+  m.def("apply_permutation", [](torch::Tensor row_pointers, torch::Tensor column_index, torch::Tensor perm) {
+    auto rp = row_pointers.to(torch::kCPU, torch::kInt).contiguous();
+    auto col = column_index.to(torch::kCPU, torch::kInt).contiguous();
+    auto p = perm.to(torch::kCPU, torch::kInt).contiguous();
+    const int64_t N = rp.numel() - 1, E = col.numel();
+    TORCH_CHECK(p.numel() == N, "perm must have num_nodes entries");
+    auto rp2 = torch::empty({N + 1}, torch::kInt), col2 = torch::empty({E}, torch::kInt);
+    check_rc(hcspmm_apply_permutation(rp.data_ptr<int>(), iptr(col), N, E, iptr(p), rp2.data_ptr<int>(), mptr(col2)),
+             "apply_permutation");
+    return std::vector<torch::Tensor>{rp2, col2};
+  }, "relabel a CSR graph with a LOI permutation -> [row_pointers, column_index]");
+  m.def("plan_info", [](torch::Tensor row_nzr) {
+    pybind11::dict d;
+    hcspmm_plan_header h;
+    if (!row_nzr.defined() || row_nzr.numel() < HCSPMM_PLAN_HEADER_WORDS || row_nzr.scalar_type() != torch::kInt) return d;
+    auto host = row_nzr.slice(0, 0, HCSPMM_PLAN_HEADER_WORDS).cpu().contiguous();
+    std::memcpy(&h, host.data_ptr<int>(), sizeof(h));
+    if (h.magic != HCSPMM_PLAN_MAGIC) return d;
+    d["n_tasks"] = h.n_tasks; d["n_dense"] = h.n_dense; d["n_split_rows"] = h.n_split_rows;
+    d["n_partials"] = h.n_partials; d["nnz_sparse"] = h.nnz_sparse; d["nnz_dense"] = h.nnz_dense;
+    d["uniq_dense"] = h.uniq_dense; d["split_threshold"] = h.split_threshold; d["segment_len"] = h.segment_len;
+    return d;
+  }, "fields of the launch plan carried in row_nzr ({} for the reference's [0] placeholder)");
 }

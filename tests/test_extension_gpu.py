@@ -101,3 +101,23 @@ def test_extension_as_shipped_rule_and_side_stream(HCSPMM, oracle_mod):
         Z = HCSPMM.forward(Xd, rp_d, col_d, *outs)[0]
     s.synchronize()
     assert np.array_equal(Z.cpu().numpy(), oracle_mod.spmm_f32(rp, col, X))
+
+
+def test_extension_host_utilities(HCSPMM):
+    """LOI reorder / permutation / plan_info through the compiled module (host side, no GPU needed)."""
+    import glob
+    gold = os.path.join(ROOT, "tests", "golden")
+    for path in sorted(glob.glob(os.path.join(gold, "loi_*.npz"))):
+        g = np.load(path)
+        rp, col = torch.from_numpy(g["row_pointers"]), torch.from_numpy(g["column_index"])
+        perm, sizes = HCSPMM.loi_reorder(rp, col)
+        assert np.array_equal(perm.numpy(), g["order"]) and np.array_equal(sizes.numpy(), g["group_sizes"])
+        perm_n, _ = HCSPMM.loi_reorder(rp, col, 1)
+        assert np.array_equal(perm_n.numpy(), g["order_new"])
+        rp2, col2 = HCSPMM.apply_permutation(rp, col, perm)
+        assert rp2.numel() == rp.numel() and int(rp2[-1]) == col.numel() and col2.numel() == col.numel()
+    rp, col = graphs.planted_dense_graph(400, seed=3)
+    outs = HCSPMM.preprocess(torch.from_numpy(col), torch.from_numpy(rp), 400, len(col), 25)
+    info = HCSPMM.plan_info(outs[4])
+    assert info["n_dense"] == int(outs[3].sum()) and info["nnz_sparse"] + info["nnz_dense"] == len(col)
+    assert HCSPMM.plan_info(torch.zeros(1, dtype=torch.int32)) == {}

@@ -1,0 +1,123 @@
+// capi_smoke.cpp -- a consumer of libhcspmm.so with NO Python and NO torch: plain C++ + the HIP
+// runtime, exactly what include/hcspmm.h promises (raw pointers, sizes, a stream).  Builds a small
+// graph, runs the host preprocess + plan, uploads, calls hcspmm_forward on its own stream (planned and
+// plan-free), and checks both against a host loop with integer-valued features (exact in fp32).
+// Built and run by tests/test_capi_native.py:  hipcc capi_smoke.cpp -I include -L csrc -lhcspmm
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <cstdlib>
+#include <vector>
+
+#include "hcspmm.h"
+
+#define HIP_OK(x)                                                                  \
+  do {                                                                             \
+    hipError_t e_ = (x);                                                           \
+    if (e_ != hipSuccess) {                                                        \
+      std::fprintf(stderr, "HIP error %d at %s:%d\n", (int)e_, __FILE__, __LINE__); \
+      return 2;                                                                    \
+    }                                                                              \
+  } while (0)
+#define HC_OK(x)                                                                              \
+  do {                                                                                        \
+    int r_ = (x);                                                                             \
+    if (r_ != HCSPMM_OK) {                                                                    \
+      std::fprintf(stderr, "hcspmm error %d (%s) at %s:%d\n", r_, hcspmm_strerror(r_), __FILE__, __LINE__); \
+      return 3;                                                                               \
+    }                                                                                         \
+  } while (0)
+
+template <typename T>
+static T* upload(const std::vector<T>& v) {
+  T* d = nullptr;
+  if (hipMalloc(&d, sizeof(T) * (v.empty() ? 1 : v.size())) != hipSuccess) return nullptr;
+  if (!v.empty() && hipMemcpy(d, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  return d;
+}
+
+int main() {
+  const int64_t N = 1000 + 7;  // not a multiple of 16
+  const int D = 48;
+  // graph: planted 16-row groups sharing 12 columns (dense-tile windows), every 5th window random and wider
+  // (sparse-row windows), one hub row (split + fix-up)
+  std::vector<int32_t> rowptr(N + 1, 0), col;
+  uint64_t rng = 88172645463325252ull;
+  auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
+  for (int64_t w = 0; w * 16 < N; ++w) {
+    std::vector<int32_t> shared_cols;
+    for (int k = 0; k < 12; ++k) shared_cols.push_back((int32_t)(next() % N));
+    for (int64_t r = w * 16; r < N && r < w * 16 + 16; ++r) {
+      std::vector<char> seen(N, 0);
+      std::vector<int32_t> mine;
+      auto add = [&](int32_t c) { if (!seen[c]) { seen[c] = 1; mine.push_back(c); } };
+      if (r == 3) for (int k = 0; k < 900; ++k) add((int32_t)(next() % N));          // hub row
+      else if (w % 5 == 4) for (int k = 0; k < 9; ++k) add((int32_t)(next() % N));   // unstructured window
+      else for (int32_t c : shared_cols) if (next() % 2) add(c);
+      std::vector<int32_t> sorted;
+      for (int64_t c = 0; c < N; ++c) if (seen[c]) sorted.push_back((int32_t)c);
+      col.insert(col.end(), sorted.begin(), sorted.end());
+      rowptr[r + 1] = (int32_t)col.size();
+    }
+  }
+  const int64_t E = (int64_t)col.size(), W = (N + 15) / 16;
+  std::vector<int32_t> bp(W), ht(W), e2c(E), e2r(E);
+  HC_OK(hcspmm_preprocess_host(rowptr.data(), col.data(), N, E, HCSPMM_RULE_INTENDED, 2, bp.data(), e2c.data(), e2r.data(),
+                               ht.data()));
+  int64_t words = 0;
+  hcspmm_plan_params pp = {256, 128};  // make the hub row split
+  HC_OK(hcspmm_plan_words(rowptr.data(), N, E, bp.data(), ht.data(), &pp, &words));
+  std::vector<int32_t> plan((size_t)words);
+  HC_OK(hcspmm_plan_build(rowptr.data(), col.data(), N, E, bp.data(), e2c.data(), ht.data(), &pp, plan.data(), words));
+  hcspmm_plan_header header;
+  std::memcpy(&header, plan.data(), sizeof(header));
+  HC_OK(hcspmm_plan_check(&header, N, E));
+  if (header.n_dense == 0 || header.n_tasks == 0 || header.n_split_rows != 1) {
+    std::fprintf(stderr, "unexpected plan: dense %d tasks %d split %d\n", header.n_dense, header.n_tasks, header.n_split_rows);
+    return 4;
+  }
+
+  std::vector<float> X((size_t)N * D), want((size_t)N * D, 0.0f);
+  for (int64_t i = 0; i < N; ++i)
+    for (int d = 0; d < D; ++d) X[(size_t)i * D + d] = (float)((i * 7 + d) % 61);
+  for (int64_t r = 0; r < N; ++r)
+    for (int32_t e = rowptr[r]; e < rowptr[r + 1]; ++e)
+      for (int d = 0; d < D; ++d) want[(size_t)r * D + d] += X[(size_t)col[e] * D + d];
+
+  int32_t *rp_d = upload(rowptr), *col_d = upload(col), *bp_d = upload(bp), *ht_d = upload(ht), *e2c_d = upload(e2c),
+          *e2r_d = upload(e2r), *plan_d = upload(plan);
+  float* X_d = upload(X);
+  float* Z_d = nullptr;
+  HIP_OK(hipMalloc(&Z_d, sizeof(float) * (size_t)N * D));
+  const size_t ws_bytes = hcspmm_workspace_bytes(&header, D);
+  void* ws_d = nullptr;
+  if (ws_bytes) HIP_OK(hipMalloc(&ws_d, ws_bytes));
+  hipStream_t stream;
+  HIP_OK(hipStreamCreate(&stream));
+  std::vector<float> got((size_t)N * D);
+  for (int pass = 0; pass < 2; ++pass) {  // 0: planned, 1: plan-free (the reference's placeholder convention)
+    HIP_OK(hipMemsetAsync(Z_d, 0xff, sizeof(float) * (size_t)N * D, stream));
+    HC_OK(hcspmm_forward(X_d, Z_d, rp_d, col_d, bp_d, e2c_d, e2r_d, ht_d, pass == 0 ? plan_d : nullptr,
+                         pass == 0 ? &header : nullptr, N, E, D, pass == 0 ? ws_d : nullptr, pass == 0 ? ws_bytes : 0,
+                         (void*)stream));
+    HIP_OK(hipMemcpyAsync(got.data(), Z_d, sizeof(float) * got.size(), hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    for (size_t i = 0; i < got.size(); ++i)
+      if (got[i] != want[i]) {
+        std::fprintf(stderr, "pass %d mismatch at %zu: %g vs %g\n", pass, i, got[i], want[i]);
+        return 5;
+      }
+  }
+  // argument errors come back as codes, not crashes
+  if (hcspmm_forward(X_d, Z_d, rp_d, col_d, bp_d, e2c_d, e2r_d, ht_d, plan_d, &header, N + 1, E, D, ws_d, ws_bytes, stream) !=
+      HCSPMM_EPLAN)
+    return 6;
+  if (ws_bytes && hcspmm_forward(X_d, Z_d, rp_d, col_d, bp_d, e2c_d, e2r_d, ht_d, plan_d, &header, N, E, D, nullptr, 0, stream) !=
+                      HCSPMM_EWORKSPACE)
+    return 7;
+  std::printf("capi_smoke ok: N=%lld E=%lld dense_windows=%d tasks=%d split_rows=%d\n", (long long)N, (long long)E,
+              header.n_dense, header.n_tasks, header.n_split_rows);
+  return 0;
+}

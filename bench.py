@@ -264,7 +264,11 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "hcspmm::hybrid_plan_kernel (+ fixup_kernel)", "kernel_ms": kern_ms,
-                         "algorithmic_bytes": b_alg},
+                         "algorithmic_bytes": b_alg,
+                         "traffic_gbs": (traffic / (kern_ms * 1e-3) / 1e9) if traffic else None,
+                         "note": "achieved counts every gathered X row (SURVEY 8d); frac > 1 means rows were served by "
+                                 "L2 / Infinity Cache instead of HBM -- `traffic` is what actually crossed the fabric "
+                                 "(PMC, profiles/), and the launch is bound by that"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(rp, col, X_local.cpu().numpy(), D)

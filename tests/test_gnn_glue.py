@@ -162,3 +162,18 @@ def test_driver_end_to_end_on_example_dataset(model, capsys, monkeypatch):
     with torch.no_grad():
         logp = net()
     assert logp.shape == (600, 22) and torch.isfinite(logp).all()
+
+
+def test_reference_style_star_imports_resolve_both_module_names():
+    """The reference driver does `import HCSPMM`, `from GNN_model import *`, then calls
+    `HYGNN.preprocess(...)` (HC-SpMM_main.py:13-15,52) -- the old module name, never imported there.
+    With our GNN_model the star import brings `HYGNN` along, so that line works as written."""
+    _pkg_imports()
+    ns = {}
+    exec("import HCSPMM\nfrom dataset import *\nfrom GNN_model import *\nfrom config import *", ns)
+    assert ns["HYGNN"] is ns["HCSPMM"] and callable(ns["HYGNN"].preprocess)
+    assert ns["BLK_H"] == 16 and ns["BLK_W"] == 8
+    for name in ("HCSPMM_dataset", "SAG", "GCNConv", "GINConv", "HCSPMMFunction_SAG", "HCSPMMFunction",
+                 "HCSPMMFunctionFixed32", "HCSPMMFunctionFinal", "HCSPMMFunctionFirst", "HCSPMMFunction_GINFixed32",
+                 "HCSPMMFunction_GINFirst", "HCSPMMFunction_GINFinal", "gen_test_tensor"):
+        assert name in ns, name

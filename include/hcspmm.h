@@ -68,7 +68,8 @@ int hcspmm_preprocess_host(const int32_t* row_pointers_h, const int32_t* column_
 /* ------------------------------------------------------------------------------------------
  * Launch plan (host build, device resident).  New on MI355X: the reference branches per thread
  * block on hybrid_type (K.cu:960,1039) with one block per window; here the host turns the
- * classified windows into (a) length-sorted sparse-row tasks, long rows split into segments, and
+ * classified windows into (a) sparse-row tasks ordered by power-of-two length class (row order inside a
+ * class), long rows split into segments, and
  * (b) packed dense-tile windows (sorted unique columns + 0/1 tile masks in MFMA lane order).
  * The blob travels in the reference's reserved `row_nzr` tensor slot (K.cu:405: row_nzr/col_nzr
  * are [0] placeholders that every forward receives and never reads).
@@ -90,7 +91,7 @@ typedef struct hcspmm_plan_header {
   int32_t num_windows;      /* W */
   int32_t split_threshold;  /* rows with more entries than this are split ... */
   int32_t segment_len;      /* ... into segments of this many entries */
-  int32_t n_tasks;          /* sparse-row tasks (one per whole row or row segment), length-sorted */
+  int32_t n_tasks;          /* sparse-row tasks (one per whole row or row segment), by descending length class */
   int32_t n_dense;          /* dense-tile windows */
   int32_t n_split_rows;     /* rows whose partial sums are combined by the fix-up pass */
   int32_t n_partials;       /* partial-sum slots (rows of the workspace) */
@@ -102,8 +103,8 @@ typedef struct hcspmm_plan_header {
   int32_t nnz_dense;        /* entries handled by the dense-tile path */
   int32_t uniq_dense;       /* sum of unique columns over dense windows (gathered X rows) */
   int32_t max_dense_k;      /* largest padded K (8*blockPartition) among dense windows */
-  int32_t n_len_gt[5];      /* tasks longer than 16, 32, 64, 128, 256 entries (tasks are length-sorted,
-                               so these are prefix sizes: the launch can hand the n longest tasks to
+  int32_t n_len_gt[5];      /* tasks longer than 16, 32, 64, 128, 256 entries (class boundaries are powers
+                               of two, so these are prefix sizes of the task list: the launch can hand the n longest tasks to
                                whole waves -- "wide" tasks -- at any of these thresholds) */
   int32_t reserved[7];
 } hcspmm_plan_header;
@@ -143,8 +144,9 @@ int32_t hcspmm_wide_threshold(const hcspmm_plan_header* header_h, int embedding_
 
 /* ------------------------------------------------------------------------------------------
  * forward: Z = A * X.  Replaces the launchers spmm_forward_plus K.cu:410, spmm_forward_plus_more :457,
- * spmm_forward_plus_fixed32 :500, spmm_forward_plus_fixed64 :553 (bindings B.cpp:194-308; Python names forward / forward_more / forward_fixed32 /
- * forward_fixed64 and the backward* aliases B.cpp:516-523) and the kernels
+ * spmm_forward_plus_fixed32 :500, spmm_forward_plus_fixed64 :553 (bindings B.cpp:194-308; Python names
+ * forward / forward_more / forward_fixed32 / forward_fixed64 and the backward* aliases B.cpp:516-523) and
+ * the kernels
  * spmm_forward_cuda_kernel_arbi_warps_hybrid_{adaptive,adaptive_more,32,64} K.cu:919-1637.
  * One entry point serves every embedding_dim (the fixed32/fixed64 variants are the same math).
  *

@@ -127,6 +127,8 @@ extern "C" int hcspmm_forward_strided(const float* X, int64_t ldx, float* Z, int
     a.plan = plan_d;
     a.off_tasks = ph->off_tasks;
     a.n_tasks = ph->n_tasks;
+    a.n_tiny = ph->n_tiny;
+    a.tiny_wgs = 0;
     a.off_dense_index = ph->off_dense_index;
     a.off_dense_pack = ph->off_dense_pack;
     a.n_dense = ph->n_dense;

@@ -11,6 +11,9 @@
 //             with -1) and, per 4-column k-step, the 64-bit lane mask of the 16x4 0/1 tile in
 //             v_mfma_f32_16x16x4_f32 A-operand order (lane = 16*(k%4) + row);
 //   fixups  : (row, first partial slot, segment count) for every split row.
+// The last n_tiny tasks (those of at most two entries: on low-degree graphs the great majority) carry
+// their column indices INSIDE the descriptor -- (row or -(slot+1), index0, length, index1), absent
+// indices -1 -- so that the kernel needs one memory round trip, not two, before it can gather.
 // Blob layout (int32 words): header[32] | tasks[n_tasks][4] | dense_index[n_dense][4] |
 // dense_pack[...] | fixups[n_split_rows][4].  All section offsets are multiples of 4 words.
 #include <algorithm>
@@ -154,6 +157,7 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
   // which costs a few % on low-degree graphs where X and Z live in HBM, not in the Infinity Cache;
   // merging all rows <= 16 entries into ONE row-ordered class is worse, profiles/r01/ab_merge_short.log).
   int32_t len_gt[5] = {0, 0, 0, 0, 0};
+  int64_t n_tiny = 0;
   {
     auto cls = [](int32_t len) {  // 0 -> 0, 1 -> 1, 2 -> 2, 3..4 -> 3, 5..8 -> 4, 9..16 -> 5, 17..32 -> 6, ...
       int c = 0;
@@ -171,6 +175,14 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
     int32_t* out = plan + L.off_tasks;
     for (const Task& t : tasks) {
       const int64_t p = start[(size_t)(n_cls - 1 - cls(t.len))]++;
+      if (t.len <= HCSPMM_TINY_LEN) {  // classes 2, 1, 0: the tail of the list
+        ++n_tiny;
+        out[4 * p + 0] = t.slot < 0 ? t.row : -(t.slot + 1);
+        out[4 * p + 1] = t.len >= 1 ? col[t.e0] : -1;
+        out[4 * p + 2] = t.len;
+        out[4 * p + 3] = t.len >= 2 ? col[t.e0 + 1] : -1;
+        continue;
+      }
       out[4 * p + 0] = t.row;
       out[4 * p + 1] = t.e0;
       out[4 * p + 2] = t.len;
@@ -230,6 +242,7 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
   h.uniq_dense = (int32_t)uniq_total;
   h.max_dense_k = L.max_dense_k;
   for (int b = 0; b < 5; ++b) h.n_len_gt[b] = len_gt[b];
+  h.n_tiny = (int32_t)n_tiny;
   static_assert(sizeof(hcspmm_plan_header) == HCSPMM_PLAN_HEADER_WORDS * 4, "header size");
   std::memcpy(plan, &h, sizeof(h));
   return HCSPMM_OK;
@@ -240,6 +253,7 @@ extern "C" int hcspmm_plan_check(const hcspmm_plan_header* h, int64_t N, int64_t
   if (h->magic != HCSPMM_PLAN_MAGIC || h->version != HCSPMM_PLAN_VERSION) return HCSPMM_EPLAN;
   if (h->num_nodes != N || h->num_edges != E) return HCSPMM_EPLAN;
   if (h->n_tasks < 0 || h->n_dense < 0 || h->n_split_rows < 0 || h->n_partials < 0) return HCSPMM_EPLAN;
+  if (h->n_tiny < 0 || h->n_tiny > h->n_tasks) return HCSPMM_EPLAN;
   if (h->off_tasks < HCSPMM_PLAN_HEADER_WORDS || h->off_dense_index < h->off_tasks ||
       h->off_dense_pack < h->off_dense_index || h->off_fixups < h->off_dense_pack ||
       h->total_words < h->off_fixups)

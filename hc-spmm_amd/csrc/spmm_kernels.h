@@ -19,9 +19,11 @@ struct PlanArgs {
   int off_fixups, n_split_rows;
   int N, D;
   int n_wide;                          // the n_wide longest tasks are summed by whole waves
+  int n_tiny;                          // the last n_tiny tasks carry their (<= 2) indices inline
   int panel_cols;                      // feature columns per sparse pass (D = one pass; 32 = panel-major)
   int sparse_wgs_pp, dense_vec;        // filled by the launcher
   int wide_wgs, sparse_wgs, n_panels;  // filled by the launcher
+  int tiny_wgs;                        // filled by the launcher: workgroups of the tiny-task region (per panel)
 };
 
 // Arguments of the plan-free launch: the reference's seven graph tensors as they are.

@@ -69,6 +69,9 @@ constexpr int kThreads = kWaves * 64;
 #ifndef HCSPMM_DENSE_B
 #define HCSPMM_DENSE_B 8   // k-steps (row loads in flight per lane) per batch on the dense-tile path
 #endif
+#ifndef HCSPMM_TINY_T
+#define HCSPMM_TINY_T 2    // tiny tasks (<= 2 entries) a lane group handles at once (2 vs 4 vs 8: profiles/r01/ab_tiny_tasks.log)
+#endif
 #ifndef HCSPMM_MIN_WAVES_PER_SIMD
 #define HCSPMM_MIN_WAVES_PER_SIMD 4  // <= 128 registers per lane (measured best with U = B = 8: profiles/r01/ab_u_b_mw_v2.log)
 #endif
@@ -183,6 +186,62 @@ __device__ __forceinline__ void sparse_task(const float* __restrict__ X, float* 
 }
 
 // ------------------------------------------------------------------------------------------
+// Tiny tasks (at most two entries, indices inline in the descriptor: hcspmm.h n_tiny).  On a low-degree
+// graph these are most of the rows, and a wave that handles 64/L of them is a chain of dependent round
+// trips (descriptor -> indices -> rows -> store) with one or two loads in flight per lane: latency, not
+// bandwidth, sets the time (tools/lowdeg_breakdown.py).  Here each lane group takes T tasks at once: T
+// independent descriptor loads, then up to 2T independent row loads, then T stores -- two round trips
+// per T tasks.  The sum is 0 + x[index0] + x[index1] in that order: the sequential CSR order.
+// ------------------------------------------------------------------------------------------
+template <int L, int VEC, int T>
+__device__ __forceinline__ void tiny_tasks(const PlanArgs& a, int first, int c0, int cend, int lane) {
+  typedef typename VecT<VEC>::type vec_t;
+  constexpr int R = 64 / L;
+  const int g = lane / L, s = lane & (L - 1);
+  const int4* tasks = reinterpret_cast<const int4*>(a.plan + a.off_tasks);
+  int4 d[T];
+  bool any1 = false, any2 = false;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int tid = first + t * R + g;  // consecutive tasks (= ascending rows) across the lane groups
+    d[t] = (tid < a.n_tasks) ? tasks[tid] : int4{0, -1, -1, -1};  // .z < 0: no task
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    any1 |= d[t].y >= 0;
+    any2 |= d[t].w >= 0;
+  }
+  any1 = __builtin_amdgcn_ballot_w64(any1) != 0;  // wave-uniform: a wave inside the 0- or 1-entry class issues
+  any2 = __builtin_amdgcn_ballot_w64(any2) != 0;  // no loads for the absent entries
+  for (int pbase = c0; pbase < cend; pbase += L * VEC) {
+    const int c = pbase + s * VEC;
+    const bool cok = c < cend;
+    const int csafe = cok ? c : 0;
+    vec_t v0[T], v1[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) v0[t] = v1[t] = vzero<VEC>();
+    if (any1) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) v0[t] = *reinterpret_cast<const vec_t*>(a.X + (size_t)max(d[t].y, 0) * a.ldx + csafe);
+    }
+    if (any2) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) v1[t] = *reinterpret_cast<const vec_t*>(a.X + (size_t)max(d[t].w, 0) * a.ldx + csafe);
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      vec_t acc = vzero<VEC>();
+      if (d[t].y >= 0) acc += v0[t];
+      if (d[t].w >= 0) acc += v1[t];
+      if (cok && d[t].z >= 0) {
+        float* dst = (d[t].x >= 0) ? a.Z + (size_t)d[t].x * a.ldz : a.partial + (size_t)(-(d[t].x + 1)) * (size_t)a.D;
+        store_out(reinterpret_cast<vec_t*>(dst + c), acc);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Dense-tile unit: one wave = (dense window, panel of 16*VEC feature columns).
 // MFMA operand maps (v_mfma_f32_16x16x4_f32): lane l supplies A[i = l & 15][k = l >> 4] and
 // B[k = l >> 4][j = l & 15]; accumulator register r of lane l is D[4*(l >> 4) + r][l & 15].
@@ -250,11 +309,14 @@ __device__ __forceinline__ void dense_unit(const float* __restrict__ X, float* _
 
 // ------------------------------------------------------------------------------------------
 // Planned hybrid kernel: ONE launch covers both sub-paths (as the reference's single launch
-// does, K.cu:960/1039) -- workgroups [0, wide_wgs) run wide sparse tasks, [wide_wgs, sparse_wgs) ordinary ones, the rest dense units.
+// does, K.cu:960/1039) -- per column panel, workgroups [0, wide_wgs) run wide sparse tasks, then ordinary
+// ones, then tiny ones (the last tiny_wgs); after all sparse panels come the dense units.
 // ------------------------------------------------------------------------------------------
 // UNROLL row loads in flight per lane, MINW waves per SIMD the register budget must allow.  With the
 // branch-free batches <8, 4> is best for throughput- and latency-bound launches alike
 // (profiles/r01/ab_u_b_mw_v2.log; before them <4, 8> won: profiles/r01/ab_u_b_mw.log).
+__device__ __forceinline__ int sparse_wgs_pp_ordinary_end(const PlanArgs& a) { return a.sparse_wgs_pp - a.tiny_wgs; }
+
 template <int L, int VEC, int UNROLL, int MINW>
 __global__ __launch_bounds__(kThreads, MINW) void hybrid_plan_kernel(PlanArgs a) {
 #if HCSPMM_LDS_STAGE
@@ -281,13 +343,18 @@ __global__ __launch_bounds__(kThreads, MINW) void hybrid_plan_kernel(PlanArgs a)
       float* dst = (t.w < 0) ? a.Z + (size_t)t.x * a.ldz : a.partial + (size_t)t.w * (size_t)a.D;
       sparse_task<L, VEC, true, UNROLL>(a.X, dst, a.col, __builtin_amdgcn_readfirstlane(t.y),
                                         __builtin_amdgcn_readfirstlane(t.z), a.ldx, c0, cend, lane, lds_stage);
+    } else if (b >= sparse_wgs_pp_ordinary_end(a)) {
+      constexpr int R = 64 / L;
+      const int first = a.n_tasks - a.n_tiny + ((b - sparse_wgs_pp_ordinary_end(a)) * kWaves + wave) * (R * HCSPMM_TINY_T);
+      if (first >= a.n_tasks) return;
+      tiny_tasks<L, VEC, HCSPMM_TINY_T>(a, first, c0, cend, lane);
     } else {
       constexpr int R = 64 / L;
       const int g = lane / L;
       const int tid = a.n_wide + ((b - a.wide_wgs) * kWaves + wave) * R + g;
       int e0 = 0, n = 0;
       float* dst = nullptr;
-      if (tid < a.n_tasks) {
+      if (tid < a.n_tasks - a.n_tiny) {
         const int4 t = reinterpret_cast<const int4*>(a.plan + a.off_tasks)[tid];
         e0 = t.y;
         n = t.z;
@@ -465,7 +532,8 @@ static hipError_t launch_plan_LV(const PlanArgs& a, hipStream_t stream) {
   PlanArgs b = a;
   b.n_wide = (R > 1) ? a.n_wide : 0;  // with one lane group per wave a wide task is an ordinary one
   b.wide_wgs = (b.n_wide + kWaves - 1) / kWaves;
-  b.sparse_wgs_pp = b.wide_wgs + (a.n_tasks - b.n_wide + kWaves * R - 1) / (kWaves * R);
+  b.tiny_wgs = (a.n_tiny + kWaves * R * HCSPMM_TINY_T - 1) / (kWaves * R * HCSPMM_TINY_T);
+  b.sparse_wgs_pp = b.wide_wgs + (a.n_tasks - a.n_tiny - b.n_wide + kWaves * R - 1) / (kWaves * R) + b.tiny_wgs;
   const int n_col_panels = (a.D + a.panel_cols - 1) / a.panel_cols;
   b.sparse_wgs = b.sparse_wgs_pp * n_col_panels;
   if (b.sparse_wgs_pp == 0) b.sparse_wgs_pp = 1;  // divisor in the kernel

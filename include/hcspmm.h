@@ -79,7 +79,8 @@ int hcspmm_preprocess_host(const int32_t* row_pointers_h, const int32_t* column_
  * read-back).
  * ---------------------------------------------------------------------------------------- */
 #define HCSPMM_PLAN_MAGIC 0x48435350 /* "HCSP" */
-#define HCSPMM_PLAN_VERSION 3
+#define HCSPMM_PLAN_VERSION 4
+#define HCSPMM_TINY_LEN 2 /* tasks of at most this many entries carry their indices in the descriptor */
 #define HCSPMM_PLAN_HEADER_WORDS 32
 
 typedef struct hcspmm_plan_header {
@@ -106,7 +107,9 @@ typedef struct hcspmm_plan_header {
   int32_t n_len_gt[5];      /* tasks longer than 16, 32, 64, 128, 256 entries (class boundaries are powers
                                of two, so these are prefix sizes of the task list: the launch can hand the n longest tasks to
                                whole waves -- "wide" tasks -- at any of these thresholds) */
-  int32_t reserved[7];
+  int32_t n_tiny;           /* the last n_tiny tasks have at most HCSPMM_TINY_LEN entries and carry their column indices
+                               inline: (row, or -(slot+1) for a row segment | index0 | length | index1), absent = -1 */
+  int32_t reserved[6];
 } hcspmm_plan_header;
 
 /* Tunables for the plan; zero-initialise for defaults. */

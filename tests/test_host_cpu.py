@@ -107,6 +107,31 @@ def _decode_plan(plan):
     return h, tasks, dindex, fix
 
 
+def _expand_tiny(h, tasks, fix, rp, col):
+    """The last n_tiny descriptors are (row | -(slot+1), index0, length, index1): turn them back into
+    (row, e0, length, slot) after checking the inline indices against the CSR arrays."""
+    tasks = tasks.copy()
+    slot_row = {}
+    for row, s0, ns, _ in fix:
+        for s in range(s0, s0 + ns):
+            slot_row[s] = row
+    first = h.n_tasks - h.n_tiny
+    assert np.all(tasks[:first, 2] > 2) and np.all(tasks[first:, 2] <= 2)
+    for i in range(first, h.n_tasks):
+        x, i0, ln, i1 = tasks[i]
+        slot = -1 if x >= 0 else -(x + 1)
+        row = x if x >= 0 else slot_row[slot]
+        seg = col[rp[row]:rp[row + 1]]
+        if ln == 0:
+            assert (i0, i1) == (-1, -1) and slot < 0
+            e0 = rp[row]
+        else:
+            e0 = rp[row] + int(np.searchsorted(seg, i0))
+            assert col[e0] == i0 and (i1 == (col[e0 + 1] if ln == 2 else -1))
+        tasks[i] = (row, e0, ln, slot)
+    return tasks
+
+
 @pytest.mark.parametrize("name,gen", GRAPHS[:4], ids=[g[0] for g in GRAPHS[:4]])
 def test_plan_covers_every_entry_exactly_once(name, gen):
     rp, col = gen()
@@ -114,6 +139,7 @@ def test_plan_covers_every_entry_exactly_once(name, gen):
     bp, e2c, e2r, ht, plan_t, _ = _pre(rp, col, 0)
     plan = plan_t.numpy()
     h, tasks, dindex, fix = _decode_plan(plan)
+    tasks = _expand_tiny(h, tasks, fix, rp, col)
     assert h.magic == Header.MAGIC and h.num_nodes == N and h.num_edges == E and h.total_words == len(plan)
     ht = ht.numpy()
     cover = np.zeros(E, np.int32)
@@ -187,6 +213,28 @@ def test_plan_splits_hub_rows(capi):
     assert tasks[:8, 2].tolist() == [256] * 7 + [208] or sorted(tasks[:8, 2].tolist(), reverse=True) == [256] * 7 + [208]
     ws = capi.lib().hcspmm_workspace_bytes(ctypes.byref(h), 128)
     assert ws == 8 * 128 * 4
+
+
+def test_plan_tiny_descriptors_carry_indices_inline():
+    # rows of 0/1/2 entries and a 514-entry row whose last segment (2 entries) is a tiny descriptor too
+    deg = np.array([0, 1, 2, 3, 514, 2, 0, 1] + [0] * 600, np.int64)
+    N = len(deg)
+    rp = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    rng = np.random.default_rng(4)
+    col = np.concatenate([np.sort(rng.choice(N, d, replace=False)) for d in deg if d]).astype(np.int32)
+    plan = _pre(rp, col, 2)[4].numpy()
+    h, tasks, _, fix = _decode_plan(plan)
+    assert h.n_tiny == int((deg <= 2).sum()) + 1 and fix.tolist() == [[4, 0, 3, 0]]
+    tiny = tasks[h.n_tasks - h.n_tiny:]
+    assert tiny[:, 2].tolist() == sorted(tiny[:, 2].tolist(), reverse=True)  # classes 2, 1, 0
+    seg = tiny[tiny[:, 0] < 0]
+    assert seg.tolist() == [[-3, col[rp[4] + 512], 2, col[rp[4] + 513]]]      # slot 2 of the split row
+    assert tiny[tiny[:, 2] == 0][:, [1, 3]].tolist() == [[-1, -1]] * int((deg == 0).sum())
+    full = _expand_tiny(h, tasks, fix, rp, col)
+    cover = np.zeros(len(col), np.int32)
+    for row, e0, ln, slot in full:
+        cover[e0:e0 + ln] += 1
+    assert np.all(cover == 1)
 
 
 def test_plan_check_rejects_mismatch(capi):

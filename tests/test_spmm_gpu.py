@@ -180,6 +180,31 @@ def test_split_rows_are_deterministic_and_within_tolerance(oracle_mod, dev):
     _check(oracle_mod, g, X, Z1)  # includes: short rows still bit-identical to the sequential oracle
 
 
+def _tiny_graph(N=3000, seed=9):
+    """Mostly rows of 0, 1 and 2 entries (the descriptors that carry their indices inline), a sprinkling of
+    longer ones, and hub rows of 513 / 514 / 770 entries whose LAST segment has 1 / 2 / 2 entries."""
+    rng = np.random.default_rng(seed)
+    deg = rng.choice([0, 1, 2, 3, 7, 40], size=N, p=[0.35, 0.3, 0.2, 0.1, 0.04, 0.01])
+    deg[[5, 1700, 2999]] = [513, 514, 770]
+    rp = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    col = np.concatenate([np.sort(rng.choice(N, d, replace=False)) for d in deg if d]).astype(np.int32)
+    return rp, col
+
+
+@pytest.mark.parametrize("D", [128, 64, 32, 20, 16, 6, 3, 1])
+def test_tiny_tasks_and_tiny_segments(oracle_mod, dev, D):
+    rp, col = _tiny_graph()
+    g = Graph(rp, col, dev, rule=2)  # every window on the sparse-row path
+    h = hcspmm.plan_header(g.row_nzr)
+    deg = np.diff(rp)
+    assert h.n_tiny == int((deg <= 2).sum()) + 3 and h.n_split_rows == 3
+    X = np.random.default_rng(D).standard_normal((g.N, D)).astype(np.float32)
+    Z = g.forward(_t(X, dev))
+    _check(oracle_mod, g, X, Z)
+    Xi = (np.arange(g.N, dtype=np.float32)[:, None] + np.arange(D, dtype=np.float32)[None, :] % 3)
+    assert np.array_equal(g.forward(_t(Xi, dev)).cpu().numpy(), oracle_mod.spmm_f32(rp, col, Xi))
+
+
 @pytest.mark.parametrize("D,H", [(32, 32), (64, 64), (96, 22), (32, 7), (16, 40)])
 def test_fused_variants(oracle_mod, dev, D, H):
     rp, col = graphs.powerlaw_graph(1200, 9000, seed=6)

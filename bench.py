@@ -39,6 +39,7 @@ WORKLOADS = {
     "rd_like": (4859280, 10149830, 32, "synthetic power-law with the paper's RD size (Table II: 4.86 M nodes / 10.1 M entries), low degree"),
     "tt_like": (3771081, 22011034, 32, "synthetic power-law with the paper's TT size (3.77 M nodes / 22.0 M entries)"),
     "dp_like": (18268981, 172183984, 32, "synthetic power-law with the paper's DP size (18.3 M nodes / 172 M entries)"),
+    "yh_like": (3139988, 6280000, 32, "molecule-collection graph of the paper's YeastH order (3.1 M nodes, avg degree 2, neighbours within a few dozen ids)"),
     "products_share": (306250, 7750000, 256, "one GPU's row block of BASELINE config 4 (ogbn-products scale: 2.45 M nodes / 62 M entries over 8 GPUs); use with --virtual-world 8"),
     "powerlaw16m_share": (2000000, 32000000, 128, "one GPU's row block of BASELINE config 5 (16 M nodes / 256 M entries over 8 GPUs); use with --virtual-world 8"),
     "dense": (2000000, 0, 128, "planted 16-row groups sharing <=24 columns, dense-tile heavy (BASELINE config 5 shape, per-GPU share)"),
@@ -52,6 +53,8 @@ def make_local_block(workload, n_local, e_local, world, rank, seed=3):
         if workload in ("dense", "alldense"):
             return graphs.planted_dense_graph_fast(n_local, seed=seed, dense_fraction=0.7 if workload == "dense" else 1.0,
                                                    k_cols=20, fill=0.45, sparse_degree=16)
+        if workload == "yh_like":
+            return graphs.molecule_graph(n_local, seed=seed)
         return graphs.powerlaw_graph(n_local, e_local, seed=seed)
     # rows follow a local power law, columns a global one (cheap to generate per rank, no exchange)
     rng = np.random.default_rng(seed + 1000 * rank)
@@ -138,6 +141,7 @@ def main():
     ap.add_argument("--workload", default="reddit", choices=sorted(WORKLOADS))
     ap.add_argument("--dim", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rule", type=int, default=0, help="window classifier (hcspmm.h: 0 intended, 2 as shipped = all sparse, 3 MI355X refit)")
     ap.add_argument("--no-plan", action="store_true", help="use the plan-free (reference-convention) kernel")
     ap.add_argument("--virtual-world", type=int, default=1,
                     help="one-GPU run of ONE rank's local product in a P-GPU job: the row block references columns of "
@@ -180,7 +184,7 @@ def main():
     E = int(len(col))
     rp_d, col_d = torch.from_numpy(rp).to(dev), torch.from_numpy(col).to(dev)
     t0 = time.perf_counter()
-    bp, e2c, e2r, ht, row_nzr, col_nzr = hcspmm.preprocess(col_d, rp_d, n_local, E, (n_local + 15) // 16)
+    bp, e2c, e2r, ht, row_nzr, col_nzr = hcspmm.preprocess(col_d, rp_d, n_local, E, (n_local + 15) // 16, rule=args.rule)
     torch.cuda.synchronize()
     prep_ms = (time.perf_counter() - t0) * 1e3
     header = hcspmm.plan_header(row_nzr)
@@ -259,7 +263,7 @@ def main():
                                    % (args.workload, desc, n_local, E, D,
                                       "" if vworld == 1 else "; ONE rank of a virtual %d-GPU job (X: %d rows resident)" % (vworld, n_local * vworld)),
                        "nodes_per_gpu": n_local, "entries_per_gpu": E, "dim": D, "parallelism": "row-block shard x%d + all-gather(X) in %d column panel(s)" % (world, n_gather_panels if world > 1 else 1),
-                       "plan": (not args.no_plan), "sparse_tasks": header.n_tasks, "dense_windows": header.n_dense,
+                       "plan": (not args.no_plan), "rule": args.rule, "sparse_tasks": header.n_tasks, "dense_windows": header.n_dense,
                        "split_rows": header.n_split_rows, "preprocess_ms": prep_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

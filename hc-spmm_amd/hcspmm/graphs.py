@@ -136,6 +136,35 @@ def planted_dense_graph_fast(num_nodes, seed=0, dense_fraction=0.7, k_cols=16, f
     return _to_csr(rows, cols, N)
 
 
+def molecule_graph(num_nodes, seed=0, size_range=(10, 46), heavy_fraction=0.45):
+    """Collection of small molecule-like components laid out one after another (the shape of the
+    TU-collection datasets in the paper's Table II -- YeastH, OVCAR-8H, ...: millions of nodes, average
+    degree ~2, every neighbour within a few dozen ids): "heavy atoms" form a branched chain with a
+    few ring closures, the remaining nodes are leaves of the latest heavy atom.  Symmetric."""
+    rng = np.random.default_rng(seed)
+    N = int(num_nodes)
+    sizes = rng.integers(size_range[0], size_range[1], N // size_range[0] + 2)
+    starts = np.concatenate([[0], np.cumsum(sizes)])
+    starts = starts[starts < N]
+    idx = np.arange(N, dtype=np.int64)
+    comp_start = starts[np.searchsorted(starts, idx, side="right") - 1]
+    heavy = rng.random(N) < heavy_fraction
+    heavy[starts] = True
+
+    def last_heavy_at_or_before(i):  # i: int64 array of node ids (>= 0)
+        return np.maximum.accumulate(np.where(heavy, idx, -1))[i]
+    prev1 = last_heavy_at_or_before(np.maximum(idx - 1, 0))              # latest heavy atom before i
+    prev2 = last_heavy_at_or_before(np.maximum(prev1 - 1, 0))            # the one before that
+    prev2 = np.where(prev2 >= comp_start, prev2, prev1)
+    parent = np.where(heavy & (rng.random(N) < 0.25), prev2, prev1)
+    has_parent = idx > comp_start
+    ring_to = last_heavy_at_or_before(np.maximum(idx - 9, 0))
+    ring = heavy & (rng.random(N) < 0.12) & (ring_to >= comp_start) & (idx - 9 >= comp_start)
+    a = np.concatenate([idx[has_parent], idx[ring]])
+    b = np.concatenate([parent[has_parent], ring_to[ring]])
+    return _to_csr(np.concatenate([a, b]), np.concatenate([b, a]), N)
+
+
 def write_coo_text(path, rowptr, col):
     """Reference on-disk format: one "dst,src" line per entry, 1-based, sorted by src
     (dataset.py:52-53 reads it; LOI.cpp:493-499 needs the second field ascending)."""

@@ -25,12 +25,19 @@ inline int classify(int32_t size, uint32_t nnz, int32_t num, int rule) {
   const float dens = (float)nnz / (float)(num * HCSPMM_BLK_H * HCSPMM_BLK_W);
   const double t2 = (double)dens * 6.578043;
   const double logit = (t1 - t2) - 3.14922857;
-  if (rule == HCSPMM_RULE_MI355X) {
-    // refit on MI355X (all embedding widths pooled; profiles/r01/classifier_refit.json): on this chip
-    // the dense-tile path wins far beyond the 3090's boundary, because it moves uniq*D bytes instead
-    // of nnz*D and its per-window overhead is lower than 16 per-row tasks
-    const double z = (double)((float)size) * 0.021636670118575098 - (double)dens * 15.956873035536201 -
-                     0.07433807190619739;
+  if (rule == HCSPMM_RULE_MI355X || rule == HCSPMM_RULE_MI355X_WIDE) {
+    // refit on MI355X against this library's two sub-paths (tools/refit_classifier.py, 65536 windows,
+    // profiles/r01/classifier_refit_v2.json).  The boundary depends on the embedding width -- at D = 32 the
+    // sparse-row path (tiny tasks, 16-byte gathers) wins below ~25 % tile density, at D = 128 the dense-tile
+    // path wins for every window of more than two columns -- so there is one coefficient set per width
+    // class: z = w1*size + w2*density + b, sparse-row path when z > 0.  The narrow fit uses the density alone:
+    // its unconstrained w1 came out slightly negative (noise: the boundary sits at ~0.2 density for every K
+    // measured), which extrapolated hub windows of thousands of columns onto the dense-tile path.
+    const bool wide = rule == HCSPMM_RULE_MI355X_WIDE;
+    const double w1 = wide ? 0.030703533058157952 : 0.0;
+    const double w2 = wide ? -139.72170588602881 : -27.50482224598512;
+    const double b = wide ? 4.259271957775277 : 6.198636370393027;
+    const double z = ((double)((float)size) * w1 + (double)dens * w2) + b;
     return z > 0 ? 0 : 1;
   }
   switch (rule) {
@@ -86,7 +93,7 @@ extern "C" int hcspmm_preprocess_host(const int32_t* rowptr, const int32_t* col,
                                       int32_t* edgeToRow, int32_t* hybrid_type) {
   if (N < 0 || E < 0 || !rowptr) return HCSPMM_EINVAL;
   if (E > 0 && (!col || !edgeToColumn)) return HCSPMM_EINVAL;  // edgeToRow may be NULL (skipped)
-  if (rule < HCSPMM_RULE_INTENDED || rule > HCSPMM_RULE_MI355X) return HCSPMM_EINVAL;
+  if (rule < HCSPMM_RULE_INTENDED || rule > HCSPMM_RULE_MI355X_WIDE) return HCSPMM_EINVAL;
   if (N > INT32_MAX - 16 || E > INT32_MAX) return HCSPMM_ERANGE;
   const int64_t W = (N + HCSPMM_BLK_H - 1) / HCSPMM_BLK_H;
   if (W > 0 && (!blockPartition || !hybrid_type)) return HCSPMM_EINVAL;

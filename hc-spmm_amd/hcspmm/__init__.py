@@ -14,7 +14,8 @@ import threading
 
 import torch
 
-from .capi import (Header, PlanParams, RULE_AS_SHIPPED, RULE_INTENDED, RULE_INTENDED_GUARD, RULE_MI355X, check, lib)
+from .capi import (Header, PlanParams, RULE_AS_SHIPPED, RULE_INTENDED, RULE_INTENDED_GUARD, RULE_MI355X,
+                   RULE_MI355X_WIDE, check, lib)
 
 __all__ = [
     "preprocess", "forward", "forward_more", "forward_fixed32", "forward_fixed64", "forward_fixed32_fused",
@@ -22,7 +23,7 @@ __all__ = [
     "backward_fixed32", "backward_fixed32_fused", "backward_final_fused", "backward_fixed64",
     "backward_fixed64_fused", "backward_final_fused_64", "backward_GIN_final_fused", "loi_reorder",
     "apply_permutation", "plan_header", "forward_rect", "forward_into", "wide_threshold", "build_plan", "set_default_rule", "RULE_INTENDED", "RULE_INTENDED_GUARD",
-    "RULE_AS_SHIPPED", "RULE_MI355X",
+    "RULE_AS_SHIPPED", "RULE_MI355X", "RULE_MI355X_WIDE", "mi355x_rule",
 ]
 
 _DEFAULT_RULE = int(os.environ.get("HCSPMM_RULE", RULE_INTENDED))
@@ -30,9 +31,16 @@ _PLAN_PARAMS = PlanParams(int(os.environ.get("HCSPMM_SPLIT_THRESHOLD", 0)), int(
 
 
 def set_default_rule(rule):
-    """Classifier rule used by preprocess(): RULE_INTENDED (default), _GUARD or _AS_SHIPPED."""
+    """Classifier rule used by preprocess(): RULE_INTENDED (default), _GUARD, _AS_SHIPPED or one of the
+    MI355X refits (mi355x_rule(D))."""
     global _DEFAULT_RULE
     _DEFAULT_RULE = int(rule)
+
+
+def mi355x_rule(embedding_dim):
+    """The MI355X refit of the window classifier for this embedding width (hcspmm.h: the boundary between
+    the two sub-paths moves with D, and preprocess -- like the reference's -- is not told D)."""
+    return RULE_MI355X if int(embedding_dim) < 64 else RULE_MI355X_WIDE
 
 
 # ---------------------------------------------------------------------------------------------

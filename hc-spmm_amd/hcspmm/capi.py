@@ -9,6 +9,7 @@ RULE_INTENDED = 0
 RULE_INTENDED_GUARD = 1
 RULE_AS_SHIPPED = 2
 RULE_MI355X = 3
+RULE_MI355X_WIDE = 4
 
 OK, EINVAL, ENOMEM, EPLAN, EHIP, EWORKSPACE, ERANGE = 0, -1, -2, -3, -4, -5, -6
 

@@ -251,7 +251,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("backward_GIN_final_fused", &spmm_forward_fused, "HCSPMM SPMM backward for GIN final fused (gfx950)");
   // additions (not in the reference): classifier rule / plan tunables, LOI reorder on the host
   m.def("set_rule", [](int rule) {
-    TORCH_CHECK(rule >= HCSPMM_RULE_INTENDED && rule <= HCSPMM_RULE_MI355X, "unknown rule");
+    TORCH_CHECK(rule >= HCSPMM_RULE_INTENDED && rule <= HCSPMM_RULE_MI355X_WIDE, "unknown rule");
     g_rule = rule;
   }, "0 = intended classifier (default), 1 = with the size>32 guard, 2 = as shipped (hybrid_all_kernel.cu:262), 3 = MI355X refit");
   m.def("set_plan_params", [](int split_threshold, int segment_len) {

@@ -43,7 +43,10 @@ extern "C" {
 #define HCSPMM_RULE_AS_SHIPPED 2     /* K.cu:262 literally: float used as bool */
 #define HCSPMM_RULE_MI355X 3         /* same two features, coefficients refit on MI355X with the paper's procedure
                                         against THIS library's two sub-paths (tools/refit_classifier.py,
-                                        profiles/r01/classifier_refit.json); not a reference output */
+                                        profiles/r01/classifier_refit_v2.json) at embedding width 32: for
+                                        narrow embeddings (D < 64); not a reference output */
+#define HCSPMM_RULE_MI355X_WIDE 4    /* the same refit at embedding width 128: for D >= 64 (preprocess does not
+                                        know D -- the reference's signature has none -- so the caller picks) */
 
 const char* hcspmm_strerror(int code);
 int hcspmm_abi_version(void);

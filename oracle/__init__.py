@@ -17,7 +17,8 @@ _LIB = None
 RULE_INTENDED = 0        # paper p.7 / hybrid_all_kernel.cu:261 without the size>32 guard
 RULE_INTENDED_GUARD = 1  # hybrid_all_kernel.cu:261 literally
 RULE_AS_SHIPPED = 2      # hybrid_all_kernel.cu:262 literally (float used as bool)
-RULE_MI355X = 3          # not a reference rule: the product's MI355X refit of the same two-feature logit
+RULE_MI355X = 3          # not a reference rule: the product's MI355X refit of the same two-feature logit (narrow embeddings)
+RULE_MI355X_WIDE = 4     # ditto, fit at embedding width 128
 
 
 def build(force=False):

@@ -27,7 +27,7 @@
 #define BLK_H 16 /* K.cu via hybrid_kernel/config.h:4 */
 #define BLK_W 8  /* hybrid_kernel/config.h:5 */
 
-enum { RULE_INTENDED = 0, RULE_INTENDED_GUARD = 1, RULE_AS_SHIPPED = 2, RULE_MI355X = 3 };
+enum { RULE_INTENDED = 0, RULE_INTENDED_GUARD = 1, RULE_AS_SHIPPED = 2, RULE_MI355X = 3, RULE_MI355X_WIDE = 4 };
 
 static int cmp_i32(const void *a, const void *b) {
   int32_t x = *(const int32_t *)a, y = *(const int32_t *)b;
@@ -67,10 +67,15 @@ double hcspmm_oracle_logit(int32_t size, uint32_t nnz_window, int32_t num) {
 
 int32_t hcspmm_oracle_classify(int32_t size, uint32_t nnz_window, int32_t num, int rule) {
   double logit = hcspmm_oracle_logit(size, nnz_window, num);
-  if (rule == RULE_MI355X) { /* NOT a reference rule: the product's own MI355X refit (include/hcspmm.h), same features */
+  if (rule == RULE_MI355X || rule == RULE_MI355X_WIDE) { /* NOT reference rules: the product's own MI355X refits (include/hcspmm.h), same features */
     volatile float dens = (float)nnz_window / (float)(num * BLK_H * BLK_W);
-    volatile double z = (double)((float)size) * 0.021636670118575098 - (double)dens * 15.956873035536201;
-    return (z - 0.07433807190619739) > 0 ? 0 : 1;
+    double w1 = rule == RULE_MI355X_WIDE ? 0.030703533058157952 : 0.0;
+    double w2 = rule == RULE_MI355X_WIDE ? -139.72170588602881 : -27.50482224598512;
+    double b = rule == RULE_MI355X_WIDE ? 4.259271957775277 : 6.198636370393027;
+    volatile double a1 = (double)((float)size) * w1;
+    volatile double a2 = (double)dens * w2;
+    volatile double z = a1 + a2;
+    return (z + b) > 0 ? 0 : 1;
   }
   switch (rule) {
     case RULE_INTENDED:       return logit > 0 ? 0 : 1;                 /* K.cu:261 minus the guard; paper p.7 */

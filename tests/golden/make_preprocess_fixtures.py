@@ -25,11 +25,11 @@ if __name__ == "__main__":
     store = {}
     for name, (rp, col) in cases.items():
         store[name + "_row_pointers"], store[name + "_column_index"] = rp, col
-        for rule in (0, 1, 2, 3):
+        for rule in (0, 1, 2, 3, 4):
             bp, e2c, e2r, ht = oracle.preprocess(rp, col, rule)
             store["%s_rule%d_blockPartition" % (name, rule)] = bp
             store["%s_rule%d_hybrid_type" % (name, rule)] = ht
         store[name + "_edgeToColumn"], store[name + "_edgeToRow"] = e2c, e2r  # rule-independent
         print(name, "N", len(rp) - 1, "E", len(col), "dense windows by rule",
-              [int(store["%s_rule%d_hybrid_type" % (name, r)].sum()) for r in range(4)])
+              [int(store["%s_rule%d_hybrid_type" % (name, r)].sum()) for r in range(5)])
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "preprocess_ints.npz"), **store)

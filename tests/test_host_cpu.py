@@ -57,7 +57,7 @@ GRAPHS = [
 
 
 @pytest.mark.parametrize("name,gen", GRAPHS, ids=[g[0] for g in GRAPHS])
-@pytest.mark.parametrize("rule", [0, 1, 2, 3])
+@pytest.mark.parametrize("rule", [0, 1, 2, 3, 4])
 def test_preprocess_bit_exact_vs_oracle(oracle_mod, name, gen, rule):
     rp, col = gen()
     want = oracle_mod.preprocess(rp, col, rule)
@@ -305,7 +305,7 @@ def test_preprocess_frozen_fixture(oracle_mod, name):
     """Oracle AND product against the committed integer fixture (tests/golden/preprocess_ints.npz)."""
     g = np.load(os.path.join(GOLD, "preprocess_ints.npz"))
     rp, col = g[name + "_row_pointers"], g[name + "_column_index"]
-    for rule in (0, 1, 2, 3):
+    for rule in (0, 1, 2, 3, 4):
         o = oracle_mod.preprocess(rp, col, rule)
         p = _pre(rp, col, rule)
         for got in (o, [t.numpy() for t in p[:4]]):

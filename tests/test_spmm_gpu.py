@@ -149,7 +149,7 @@ def test_forward_parity_planned_forced_types(oracle_mod, dev, name, gen, split_f
     _check(oracle_mod, g, X, g.forward(_t(X, dev)), exact_bits=bool(force))
 
 
-@pytest.mark.parametrize("rule", [0, 1, 2, 3])
+@pytest.mark.parametrize("rule", [0, 1, 2, 3, 4])
 def test_rules_and_aliases(oracle_mod, dev, rule):
     rp, col = graphs.planted_dense_graph(800, seed=9)
     g = Graph(rp, col, dev, rule=rule)

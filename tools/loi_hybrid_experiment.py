@@ -1,6 +1,6 @@
 """Experiment: what the layout reorder (LOI) and the dense-tile path buy on MI355X for a graph that HAS
 window structure but arrives with shuffled vertex ids.  For each stage prints windows on the
-dense-tile path and the SpMM time (D = 128 and 32), for the reference's rule (0) and the MI355X refit (3)."""
+dense-tile path and the SpMM time (D = 128 and 32), for the reference's rule (0) and the MI355X refits (3 narrow, 4 wide)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "hc-spmm_amd")]
@@ -28,7 +28,7 @@ def timeit(fn, n=30):
 def measure(tag, rp, col):
     n = len(rp) - 1
     rp_d, col_d = torch.from_numpy(np.asarray(rp)).to(dev), torch.from_numpy(np.asarray(col)).to(dev)
-    for rule in (0, 3):
+    for rule in (0, 3, 4):
         outs = hcspmm.preprocess(col_d, rp_d, n, len(col), (n + 15) // 16, rule=rule)
         h = hcspmm.plan_header(outs[4])
         ts = []

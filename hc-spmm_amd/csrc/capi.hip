@@ -132,6 +132,8 @@ extern "C" int hcspmm_forward_strided(const float* X, int64_t ldx, float* Z, int
     a.off_dense_index = ph->off_dense_index;
     a.off_dense_pack = ph->off_dense_pack;
     a.n_dense = ph->n_dense;
+    a.off_dense_compact = ph->off_dense_compact;
+    a.n_dense_compact = ph->n_dense_compact;
     a.off_fixups = ph->off_fixups;
     a.n_split_rows = ph->n_split_rows;
     wide_choice(ph, D, &a.n_wide, &a.panel_cols);

@@ -10,12 +10,17 @@
 //   dense   : per dense-path window, its ascending unique columns (K = 8*blockPartition, padded
 //             with -1) and, per 4-column k-step, the 64-bit lane mask of the 16x4 0/1 tile in
 //             v_mfma_f32_16x16x4_f32 A-operand order (lane = 16*(k%4) + row);
+//   compact : dense windows of at most HCSPMM_COMPACT_K columns (the usual case on low-degree graphs) get a
+//             fixed 64-word record instead -- [window, K/4, U[32], 8 x (mask lo, mask hi), pad] -- whose
+//             address follows from the unit number, so a wave fetches everything it needs to start
+//             gathering with ONE coalesced 256-byte load (dense_index + U + masks are two dependent loads);
 //   fixups  : (row, first partial slot, segment count) for every split row.
 // The last n_tiny tasks (those of at most two entries: on low-degree graphs the great majority) carry
 // their column indices INSIDE the descriptor -- (row or -(slot+1), index0, length, index1), absent
 // indices -1 -- so that the kernel needs one memory round trip, not two, before it can gather.
 // Blob layout (int32 words): header[32] | tasks[n_tasks][4] | dense_index[n_dense][4] |
-// dense_pack[...] | fixups[n_split_rows][4].  All section offsets are multiples of 4 words.
+// dense_pack[...] | compact[n_dense_compact][64] | fixups[n_split_rows][4].  All section offsets are multiples
+// of 4 words, the compact section's of 64.
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
@@ -42,11 +47,11 @@ Resolved resolve(const hcspmm_plan_params* p) {
 inline int64_t align4(int64_t x) { return (x + 3) & ~int64_t(3); }
 
 struct Layout {
-  int64_t n_tasks = 0, n_dense = 0, n_split_rows = 0, n_partials = 0;
+  int64_t n_tasks = 0, n_dense = 0, n_compact = 0, n_split_rows = 0, n_partials = 0;
   int64_t dense_pack_words = 0;
   int64_t nnz_sparse = 0, nnz_dense = 0;
   int32_t max_dense_k = 0;
-  int64_t off_tasks = 0, off_dense_index = 0, off_dense_pack = 0, off_fixups = 0, total = 0;
+  int64_t off_tasks = 0, off_dense_index = 0, off_dense_pack = 0, off_compact = 0, off_fixups = 0, total = 0;
 };
 
 int compute_layout(const int32_t* rowptr, int64_t N, const int32_t* bp, const int32_t* ht, const Resolved& rp,
@@ -60,7 +65,8 @@ int compute_layout(const int32_t* rowptr, int64_t N, const int32_t* bp, const in
       if (bp[w] <= 0) return HCSPMM_EINVAL;
       L.n_dense++;
       const int64_t K = (int64_t)bp[w] * HCSPMM_BLK_W;
-      L.dense_pack_words += K + (K / 4) * 2;  // U[K] + one 64-bit mask per 4 columns
+      if (K <= HCSPMM_COMPACT_K) L.n_compact++;
+      else L.dense_pack_words += K + (K / 4) * 2;  // U[K] + one 64-bit mask per 4 columns
       L.nnz_dense += nnz;
       L.max_dense_k = std::max<int32_t>(L.max_dense_k, (int32_t)K);
     } else {
@@ -81,7 +87,8 @@ int compute_layout(const int32_t* rowptr, int64_t N, const int32_t* bp, const in
   L.off_tasks = HCSPMM_PLAN_HEADER_WORDS;
   L.off_dense_index = align4(L.off_tasks + 4 * L.n_tasks);
   L.off_dense_pack = align4(L.off_dense_index + 4 * L.n_dense);
-  L.off_fixups = align4(L.off_dense_pack + L.dense_pack_words);
+  L.off_compact = (L.off_dense_pack + L.dense_pack_words + 63) & ~int64_t(63);
+  L.off_fixups = align4(L.off_compact + HCSPMM_COMPACT_WORDS * L.n_compact);
   L.total = align4(L.off_fixups + 4 * L.n_split_rows);
   if (L.total > INT32_MAX) return HCSPMM_ERANGE;
   *out = L;
@@ -194,14 +201,21 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
   std::stable_sort(dense.begin(), dense.end(), [](const DenseRef& a, const DenseRef& b) { return a.K > b.K; });
   int32_t* dindex = plan + L.off_dense_index;
   int32_t* dpack = plan + L.off_dense_pack;
-  int64_t pack_off = 0, uniq_total = 0;
+  int64_t pack_off = 0, uniq_total = 0, n_compact_done = 0;
   for (size_t i = 0; i < dense.size(); ++i) {
     const int64_t w = dense[i].w;
     const int32_t K = dense[i].K, K4 = K / 4;
     const int64_t r0 = w * HCSPMM_BLK_H, r1 = std::min<int64_t>(r0 + HCSPMM_BLK_H, N);
-    int32_t* U = dpack + pack_off;
-    uint32_t* masks = reinterpret_cast<uint32_t*>(U + K);  // little-endian halves of the 64-bit masks
-    for (int32_t k = 0; k < K; ++k) U[k] = -1;
+    const bool compact = K <= HCSPMM_COMPACT_K;  // sorted by K: the compact windows are the tail of the list
+    int32_t* rec = plan + L.off_compact + HCSPMM_COMPACT_WORDS * n_compact_done;
+    int32_t* U = compact ? rec + 2 : dpack + pack_off;
+    // little-endian halves of the 64-bit masks
+    uint32_t* masks = reinterpret_cast<uint32_t*>(compact ? rec + 2 + HCSPMM_COMPACT_K : U + K);
+    if (compact) {
+      rec[0] = (int32_t)w;
+      rec[1] = K4;
+    }
+    for (int32_t k = 0; k < (compact ? HCSPMM_COMPACT_K : K); ++k) U[k] = -1;
     for (int64_t r = r0; r < r1; ++r) {
       for (int64_t e = rowptr[r]; e < rowptr[r + 1]; ++e) {
         const int32_t c = e2c[e];
@@ -213,10 +227,11 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
     }
     for (int32_t k = 0; k < K; ++k) uniq_total += U[k] >= 0;
     dindex[4 * i + 0] = (int32_t)w;
-    dindex[4 * i + 1] = (int32_t)pack_off;
+    dindex[4 * i + 1] = compact ? (int32_t)(HCSPMM_COMPACT_WORDS * n_compact_done) : (int32_t)pack_off;
     dindex[4 * i + 2] = K4;
-    dindex[4 * i + 3] = 0;
-    pack_off += K + K4 * 2;
+    dindex[4 * i + 3] = compact ? 1 : 0;  // 1: offset is relative to the compact section (the kernel does not read this entry)
+    if (compact) ++n_compact_done;
+    else pack_off += K + K4 * 2;
   }
 
   hcspmm_plan_header h;
@@ -243,6 +258,8 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
   h.max_dense_k = L.max_dense_k;
   for (int b = 0; b < 5; ++b) h.n_len_gt[b] = len_gt[b];
   h.n_tiny = (int32_t)n_tiny;
+  h.n_dense_compact = (int32_t)L.n_compact;
+  h.off_dense_compact = (int32_t)L.off_compact;
   static_assert(sizeof(hcspmm_plan_header) == HCSPMM_PLAN_HEADER_WORDS * 4, "header size");
   std::memcpy(plan, &h, sizeof(h));
   return HCSPMM_OK;
@@ -254,6 +271,9 @@ extern "C" int hcspmm_plan_check(const hcspmm_plan_header* h, int64_t N, int64_t
   if (h->num_nodes != N || h->num_edges != E) return HCSPMM_EPLAN;
   if (h->n_tasks < 0 || h->n_dense < 0 || h->n_split_rows < 0 || h->n_partials < 0) return HCSPMM_EPLAN;
   if (h->n_tiny < 0 || h->n_tiny > h->n_tasks) return HCSPMM_EPLAN;
+  if (h->n_dense_compact < 0 || h->n_dense_compact > h->n_dense || h->off_dense_compact < h->off_dense_pack ||
+      h->off_dense_compact > h->off_fixups || (h->off_dense_compact & 63) != 0)
+    return HCSPMM_EPLAN;
   if (h->off_tasks < HCSPMM_PLAN_HEADER_WORDS || h->off_dense_index < h->off_tasks ||
       h->off_dense_pack < h->off_dense_index || h->off_fixups < h->off_dense_pack ||
       h->total_words < h->off_fixups)

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "hcspmm.h"
 #include "spmm_kernels.h"
 
 namespace hcspmm {
@@ -69,9 +70,14 @@ constexpr int kThreads = kWaves * 64;
 #ifndef HCSPMM_DENSE_B
 #define HCSPMM_DENSE_B 8   // k-steps (row loads in flight per lane) per batch on the dense-tile path
 #endif
-#ifndef HCSPMM_TINY_T
-#define HCSPMM_TINY_T 2    // tiny tasks (<= 2 entries) a lane group handles at once (2 vs 4 vs 8: profiles/r01/ab_tiny_tasks.log)
-#endif
+#ifndef HCSPMM_TINY_PER_WAVE
+#define HCSPMM_TINY_PER_WAVE 8  // tiny tasks (<= 2 entries) per wave: T = 8 / (64/L) per lane group, at least 2, at most 4
+#endif                          // (D = 32: T = 2 vs 4 vs 8 in profiles/r01/ab_tiny_tasks.log; wide D: ab_tiny_tasks_wide.log;
+                                //  T = 8 costs the L = 32 build its fifth wave per SIMD: 119 instead of 94 registers)
+template <int L> struct TinyT {
+  static constexpr int per_group = HCSPMM_TINY_PER_WAVE / (64 / L);
+  static constexpr int value = per_group < 2 ? 2 : (per_group > 4 ? 4 : per_group);
+};
 #ifndef HCSPMM_MIN_WAVES_PER_SIMD
 #define HCSPMM_MIN_WAVES_PER_SIMD 4  // <= 128 registers per lane (measured best with U = B = 8: profiles/r01/ab_u_b_mw_v2.log)
 #endif
@@ -307,6 +313,77 @@ __device__ __forceinline__ void dense_unit(const float* __restrict__ X, float* _
   }
 }
 
+// Compact dense unit: a window of at most 32 (padded) columns whose whole description is one 64-word
+// record at an address that follows from the unit number (hcspmm.h n_dense_compact): lane l loads word l
+// -- one coalesced 256-byte load -- and the wave can gather: window / K4 / masks go to scalar registers
+// (v_readlane), the column list is broadcast as in dense_unit.  Two round trips per unit instead of three.
+// Same MFMA chain as dense_unit, so the same bits.
+template <int VEC, int STEPS>
+__device__ __forceinline__ void compact_steps(const float* __restrict__ X, int word, int K4, int csafe, bool cok,
+                                              size_t ldx, int lane, f32x4 (&acc)[VEC], int t_base) {
+  typedef typename VecT<VEC>::type vec_t;
+  const int kq = lane >> 4;
+  int idx[STEPS];
+  vec_t x[STEPS];
+  float a[STEPS];
+#pragma unroll
+  for (int u = 0; u < STEPS; ++u) {
+    const int t = t_base + u;
+    idx[u] = __shfl(word, 2 + 4 * t + kq, 64);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane(word, 2 + HCSPMM_COMPACT_K + 2 * t);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane(word, 3 + HCSPMM_COMPACT_K + 2 * t);
+    const unsigned long long m = ((unsigned long long)hi << 32) | lo;
+    a[u] = (t < K4 && ((m >> lane) & 1ull)) ? 1.0f : 0.0f;
+    if (t >= K4) idx[u] = -1;
+  }
+#pragma unroll
+  for (int u = 0; u < STEPS; ++u) x[u] = *reinterpret_cast<const vec_t*>(X + (size_t)max(idx[u], 0) * ldx + csafe);
+#pragma unroll
+  for (int u = 0; u < STEPS; ++u) {
+    if (!(cok && idx[u] >= 0)) x[u] = vzero<VEC>();
+    if (t_base + u < K4) {  // wave-uniform
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], vget(x[u], q), acc[q], 0, 0, 0);
+    }
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void dense_compact_unit(const float* __restrict__ X, float* __restrict__ Z,
+                                                   const int* __restrict__ rec, int panel, int N, int D, size_t ldx,
+                                                   size_t ldz, int lane) {
+  typedef typename VecT<VEC>::type vec_t;
+  const int word = rec[lane];
+  const int window = __builtin_amdgcn_readlane(word, 0);
+  const int K4 = __builtin_amdgcn_readlane(word, 1);
+  const int kq = lane >> 4, j = lane & 15;
+  const int c = panel * 16 * VEC + j * VEC;
+  const bool cok = c < D;
+  const int csafe = cok ? c : 0;
+  f32x4 acc[VEC];
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (K4 <= 2) {
+    compact_steps<VEC, 2>(X, word, K4, csafe, cok, ldx, lane, acc, 0);
+  } else if (K4 <= 4) {
+    compact_steps<VEC, 4>(X, word, K4, csafe, cok, ldx, lane, acc, 0);
+  } else {
+    compact_steps<VEC, 8>(X, word, K4, csafe, cok, ldx, lane, acc, 0);
+  }
+  if (cok) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = window * 16 + 4 * kq + r;
+      if (row < N) {
+        vec_t o;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) vset(o, q, acc[q][r]);
+        store_out(reinterpret_cast<vec_t*>(Z + (size_t)row * ldz + c), o);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // Planned hybrid kernel: ONE launch covers both sub-paths (as the reference's single launch
 // does, K.cu:960/1039) -- per column panel, workgroups [0, wide_wgs) run wide sparse tasks, then ordinary
@@ -345,9 +422,9 @@ __global__ __launch_bounds__(kThreads, MINW) void hybrid_plan_kernel(PlanArgs a)
                                         __builtin_amdgcn_readfirstlane(t.z), a.ldx, c0, cend, lane, lds_stage);
     } else if (b >= sparse_wgs_pp_ordinary_end(a)) {
       constexpr int R = 64 / L;
-      const int first = a.n_tasks - a.n_tiny + ((b - sparse_wgs_pp_ordinary_end(a)) * kWaves + wave) * (R * HCSPMM_TINY_T);
+      const int first = a.n_tasks - a.n_tiny + ((b - sparse_wgs_pp_ordinary_end(a)) * kWaves + wave) * (R * TinyT<L>::value);
       if (first >= a.n_tasks) return;
-      tiny_tasks<L, VEC, HCSPMM_TINY_T>(a, first, c0, cend, lane);
+      tiny_tasks<L, VEC, TinyT<L>::value>(a, first, c0, cend, lane);
     } else {
       constexpr int R = 64 / L;
       const int g = lane / L;
@@ -363,9 +440,19 @@ __global__ __launch_bounds__(kThreads, MINW) void hybrid_plan_kernel(PlanArgs a)
       sparse_task<L, VEC, false, UNROLL>(a.X, dst, a.col, e0, n, a.ldx, c0, cend, lane, lds_stage);
     }
   } else {
-    const int unit = ((int)blockIdx.x - a.sparse_wgs) * kWaves + wave;
+    int unit = ((int)blockIdx.x - a.sparse_wgs) * kWaves + wave;
     if (unit >= a.n_dense * a.n_panels) return;
-    const int panel = unit / a.n_dense, di = unit - panel * a.n_dense;  // panel-major, like the sparse region
+    const int n_reg = a.n_dense - a.n_dense_compact;  // regular windows (K > 32) first, widest first
+    if (unit >= n_reg * a.n_panels) {
+      unit -= n_reg * a.n_panels;
+      const int panel = unit / a.n_dense_compact, ci = unit - panel * a.n_dense_compact;  // panel-major
+      const int* rec = a.plan + a.off_dense_compact + ci * HCSPMM_COMPACT_WORDS;
+      if (VEC >= 4 && a.dense_vec == 4) dense_compact_unit<(VEC >= 4 ? 4 : 1)>(a.X, a.Z, rec, panel, a.N, a.D, a.ldx, a.ldz, lane);
+      else if (VEC >= 2 && a.dense_vec == 2) dense_compact_unit<(VEC >= 2 ? 2 : 1)>(a.X, a.Z, rec, panel, a.N, a.D, a.ldx, a.ldz, lane);
+      else dense_compact_unit<1>(a.X, a.Z, rec, panel, a.N, a.D, a.ldx, a.ldz, lane);
+      return;
+    }
+    const int panel = unit / n_reg, di = unit - panel * n_reg;  // panel-major, like the sparse region
     const int4 d = reinterpret_cast<const int4*>(a.plan + a.off_dense_index)[di];
     const int* U = a.plan + a.off_dense_pack + d.y;
     const unsigned long long* masks = reinterpret_cast<const unsigned long long*>(U + 4 * d.z);
@@ -532,7 +619,7 @@ static hipError_t launch_plan_LV(const PlanArgs& a, hipStream_t stream) {
   PlanArgs b = a;
   b.n_wide = (R > 1) ? a.n_wide : 0;  // with one lane group per wave a wide task is an ordinary one
   b.wide_wgs = (b.n_wide + kWaves - 1) / kWaves;
-  b.tiny_wgs = (a.n_tiny + kWaves * R * HCSPMM_TINY_T - 1) / (kWaves * R * HCSPMM_TINY_T);
+  b.tiny_wgs = (a.n_tiny + kWaves * R * TinyT<L>::value - 1) / (kWaves * R * TinyT<L>::value);
   b.sparse_wgs_pp = b.wide_wgs + (a.n_tasks - a.n_tiny - b.n_wide + kWaves * R - 1) / (kWaves * R) + b.tiny_wgs;
   const int n_col_panels = (a.D + a.panel_cols - 1) / a.panel_cols;
   b.sparse_wgs = b.sparse_wgs_pp * n_col_panels;

@@ -22,7 +22,8 @@ class Header(ctypes.Structure):
         "magic", "version", "total_words", "num_nodes", "num_edges", "num_windows", "split_threshold", "segment_len",
         "n_tasks", "n_dense", "n_split_rows", "n_partials", "off_tasks", "off_dense_index", "off_dense_pack",
         "off_fixups", "nnz_sparse", "nnz_dense", "uniq_dense", "max_dense_k")] + [("n_len_gt", ctypes.c_int32 * 5),
-                                                                                  ("n_tiny", ctypes.c_int32), ("reserved", ctypes.c_int32 * 6)]
+                                                                                  ("n_tiny", ctypes.c_int32), ("n_dense_compact", ctypes.c_int32),
+                                                                                  ("off_dense_compact", ctypes.c_int32), ("reserved", ctypes.c_int32 * 4)]
 
 
 class PlanParams(ctypes.Structure):

@@ -180,6 +180,31 @@ def test_split_rows_are_deterministic_and_within_tolerance(oracle_mod, dev):
     _check(oracle_mod, g, X, Z1)  # includes: short rows still bit-identical to the sequential oracle
 
 
+@pytest.mark.parametrize("D", [128, 64, 32, 17, 4])
+def test_dense_windows_around_the_compact_record_limit(oracle_mod, dev, D):
+    """Dense windows with exactly K = 1, 2, 8, 9, 16, 25, 31, 32 (compact 64-word records) and 33, 40, 64,
+    130 (regular packs) unique columns in one graph, last window ragged (N % 16 != 0)."""
+    rng = np.random.default_rng(5)
+    Ks = [1, 2, 8, 9, 16, 25, 31, 32, 33, 40, 64, 130, 7]
+    N = 16 * len(Ks) - 5
+    rows, cols = [], []
+    for w, K in enumerate(Ks):
+        cset = np.sort(rng.choice(N, K, replace=False))
+        nrows = min(16, N - 16 * w)
+        m = rng.random((nrows, K)) < 0.4
+        m[rng.integers(0, nrows, K), np.arange(K)] = True  # every column used: exactly K unique columns
+        r, k = np.nonzero(m)
+        rows.append(16 * w + r)
+        cols.append(cset[k])
+    rp, col = graphs._to_csr(np.concatenate(rows), np.concatenate(cols), N)
+    g = Graph(rp, col, dev, force_type=1)
+    h = hcspmm.plan_header(g.row_nzr)
+    uniq = [len(np.unique(col[rp[16 * w]:rp[min(16 * w + 16, N)]])) for w in range(len(Ks))]
+    assert h.n_dense == len(Ks) and h.n_dense_compact == sum(8 * ((u + 7) // 8) <= 32 for u in uniq)
+    X = rng.standard_normal((N, D)).astype(np.float32)
+    _check(oracle_mod, g, X, g.forward(_t(X, dev)), exact_bits=True)
+
+
 def _tiny_graph(N=3000, seed=9):
     """Mostly rows of 0, 1 and 2 entries (the descriptors that carry their indices inline), a sprinkling of
     longer ones, and hub rows of 513 / 514 / 770 entries whose LAST segment has 1 / 2 / 2 entries."""

@@ -86,11 +86,12 @@ def make_local_block(workload, n_local, e_local, world, rank, seed=3):
     return np.cumsum(rp).astype(np.int32), cols.astype(np.int32)
 
 
-def algorithmic_bytes(N, E, D, header):
+def algorithmic_bytes(N, E, D, header, elem=4):
     """4*E*D row gathers + 4*N*D Z write + 4*E column ids + 4*(N+1) row pointers; for
-    dense-path windows 4*uniq_w*D instead of 4*nnz_w*D, plus 8*nnz_w (edgeToColumn + edgeToRow)."""
+    dense-path windows 4*uniq_w*D instead of 4*nnz_w*D, plus 8*nnz_w (edgeToColumn + edgeToRow).
+    (elem = bytes per feature element: 4, or 2 with --dtype f16 / bf16.)"""
     nnz_d, uniq_d = header.nnz_dense, header.uniq_dense
-    return 4.0 * (E - nnz_d) * D + 4.0 * uniq_d * D + 8.0 * nnz_d + 4.0 * N * D + 4.0 * E + 4.0 * (N + 1)
+    return float(elem) * ((E - nnz_d) * D + uniq_d * D + N * D) + 8.0 * nnz_d + 4.0 * E + 4.0 * (N + 1)
 
 
 def cpu_baseline(rp, col, X_host, D, budget_s=12.0):
@@ -141,6 +142,8 @@ def main():
     ap.add_argument("--workload", default="reddit", choices=sorted(WORKLOADS))
     ap.add_argument("--dim", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "bf16"],
+                    help="feature element type; f32 is the reference's (and BASELINE's) -- the 16-bit variants are the paper's Table VII extension")
     ap.add_argument("--rule", type=int, default=0, help="window classifier (hcspmm.h: 0 intended, 2 as shipped = all sparse, 3 MI355X refit)")
     ap.add_argument("--no-plan", action="store_true", help="use the plan-free (reference-convention) kernel")
     ap.add_argument("--virtual-world", type=int, default=1,
@@ -192,6 +195,9 @@ def main():
         row_nzr = torch.zeros(1, dtype=torch.int32, device=dev)
     torch.manual_seed(1234 + rank)
     X_local = torch.randn(n_local * vworld, D, device=dev)  # dataset.py:114 init_embedding
+    tdtype = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[args.dtype]
+    X_local = X_local.to(tdtype)
+    elem = X_local.element_size()
 
     ev_pairs = []
 
@@ -243,21 +249,21 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        b_alg = algorithmic_bytes(n_local, E, D, header)
+        b_alg = algorithmic_bytes(n_local, E, D, header, elem)
         achieved = b_alg / (kern_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and world == 1:  # measured for the one-GPU launch only
+        if os.path.exists(tpath) and world == 1 and args.dtype == "f32" and args.rule == 0:  # measured for the default one-GPU launch only
             try:
                 traffic = json.load(open(tpath)).get("%s_d%d" % (args.workload, D))
             except Exception:
                 traffic = None
         out = {
-            "metric": "GNN-aggregation SpMM edges*dim/s (A*X, fp32)",
+            "metric": "GNN-aggregation SpMM edges*dim/s (A*X, %s)" % ("fp32" if args.dtype == "f32" else args.dtype + " features, fp32 accumulation"),
             "value": total_edges * D / (elapsed / args.steps),
             "unit": "edge*dim/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo -- not a measurement)" if rehearsal else ""),
             "config": {"workload": "%s: %s; %d nodes / %d stored entries per GPU, dim %d%s"
                                    % (args.workload, desc, n_local, E, D,
@@ -275,7 +281,7 @@ def main():
                                  "(PMC, profiles/), and the launch is bound by that"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(rp, col, X_local.cpu().numpy(), D)
+            out["cpu_baseline"] = cpu_baseline(rp, col, X_local.float().cpu().numpy(), D)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

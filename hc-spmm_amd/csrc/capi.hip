@@ -22,12 +22,23 @@ int fail_hip(hipError_t e) {
 
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
-// widest per-lane access the operands allow
-int pick_vec(int D, int64_t ldx, int64_t ldz, const void* X, const void* Z, const void* ws) {
+inline int elem_bytes(int dtype) { return dtype == HCSPMM_DTYPE_F32 ? 4 : 2; }
+
+// widest per-lane access (in elements) the operands allow; the fp32 workspace is read 4*vec bytes at a time
+int pick_vec(int dtype, int D, int64_t ldx, int64_t ldz, const void* X, const void* Z, const void* ws) {
   const int64_t all = (int64_t)D | ldx | ldz;
-  if (all % 4 == 0 && aligned(X, 16) && aligned(Z, 16) && (!ws || aligned(ws, 16))) return 4;
-  if (all % 2 == 0 && aligned(X, 8) && aligned(Z, 8) && (!ws || aligned(ws, 8))) return 2;
+  const size_t eb = (size_t)elem_bytes(dtype);
+  for (int v = (dtype == HCSPMM_DTYPE_F32 ? 4 : 8); v > 1; v >>= 1) {
+    if (dtype != HCSPMM_DTYPE_F32 && v == 2) continue;  // 16-bit builds: 8, 4 or 1 elements per lane
+    if (all % v == 0 && aligned(X, v * eb) && aligned(Z, v * eb) && (!ws || aligned(ws, 4 * (size_t)v))) return v;
+  }
   return 1;
+}
+
+// the access width wide_choice assumes (from the embedding width alone, so that callers can ask ahead of a launch)
+inline int nominal_vec(int dtype, int D) {
+  if (dtype == HCSPMM_DTYPE_F32) return (D % 4 == 0) ? 4 : (D % 2 == 0) ? 2 : 1;
+  return (D % 8 == 0) ? 8 : (D % 4 == 0) ? 4 : 1;
 }
 }  // namespace
 
@@ -51,16 +62,17 @@ extern "C" const char* hcspmm_strerror(int code) {
 // pass re-reads the column indices and pays the per-task overhead again, so short-row graphs
 // (mean task length < 8) keep one pass over the full width.  HCSPMM_PANEL_COLS overrides
 // (-1: one pass; n > 0: n columns, rounded up to a multiple of 16).
-static int panel_choice(const hcspmm_plan_header* h, int D) {
+static int panel_choice(const hcspmm_plan_header* h, int D, int dtype) {
   static const int env = [] {
     const char* e = getenv("HCSPMM_PANEL_COLS");
     return e ? atoi(e) : 0;
   }();
   if (env < 0) return D;
   if (env > 0) return env >= D ? D : ((env + 15) / 16) * 16;
-  if (D < 64 || h->n_tasks <= 0) return D;
+  const int line_cols = 128 / elem_bytes(dtype);  // 32 fp32 or 64 16-bit columns: one cache line per gathered row
+  if (D < 2 * line_cols || h->n_tasks <= 0) return D;
   const double mean_len = (double)h->nnz_sparse / (double)h->n_tasks;
-  return mean_len >= 8.0 ? 32 : D;
+  return mean_len >= 8.0 ? line_cols : D;
 }
 
 // Wide-task threshold.  A lane group sums a task with U loads in flight, so a task of T entries is a
@@ -69,9 +81,9 @@ static int panel_choice(const hcspmm_plan_header* h, int D) {
 // power of two in [16, 256] not exceeding a quarter of that depth times 8: small (latency-bound)
 // launches hand every row longer than 16 entries to a whole wave, large (throughput-bound) ones
 // keep rows up to 256 entries on one lane group, in CSR order.
-static int wide_choice(const hcspmm_plan_header* h, int D, int* n_wide, int* panel_cols = nullptr) {
-  const int vec = (D % 4 == 0) ? 4 : (D % 2 == 0) ? 2 : 1;
-  const int pw = panel_choice(h, D);
+static int wide_choice(const hcspmm_plan_header* h, int D, int dtype, int* n_wide, int* panel_cols = nullptr) {
+  const int vec = nominal_vec(dtype, D);
+  const int pw = panel_choice(h, D, dtype);
   if (panel_cols) *panel_cols = pw;
   const double passes = (double)((D + pw - 1) / pw);
   int L = 4;
@@ -88,24 +100,29 @@ static int wide_choice(const hcspmm_plan_header* h, int D, int* n_wide, int* pan
   return *n_wide > 0 ? (16 << b) : INT32_MAX;
 }
 
-extern "C" int32_t hcspmm_wide_threshold(const hcspmm_plan_header* h, int D) {
-  if (D <= 0) return INT32_MAX;
-  if (!h) {  // plan-free kernel: fixed threshold (kPlanFreeWide in spmm_kernels.hip) unless a wave holds one lane group
-    const int vec = (D % 4 == 0) ? 4 : (D % 2 == 0) ? 2 : 1;
+extern "C" int32_t hcspmm_wide_threshold_typed(const hcspmm_plan_header* h, int D, int dtype) {
+  if (D <= 0 || dtype < HCSPMM_DTYPE_F32 || dtype > HCSPMM_DTYPE_BF16) return INT32_MAX;
+  if (!h) {  // plan-free kernel: fixed threshold (kPlanFreeWide in spmm_impl.h) unless a wave holds one lane group
+    const int vec = nominal_vec(dtype, D);
     return (D + vec - 1) / vec > 32 ? INT32_MAX : 64;
   }
   int n_wide = 0;
-  return wide_choice(h, D, &n_wide);
+  return wide_choice(h, D, dtype, &n_wide);
+}
+
+extern "C" int32_t hcspmm_wide_threshold(const hcspmm_plan_header* h, int D) {
+  return hcspmm_wide_threshold_typed(h, D, HCSPMM_DTYPE_F32);
 }
 
 extern "C" int hcspmm_abi_version(void) { return HCSPMM_ABI_VERSION; }
 extern "C" int hcspmm_last_hip_error(void) { return g_last_hip_error; }
 
-extern "C" int hcspmm_forward_strided(const float* X, int64_t ldx, float* Z, int64_t ldz, const int32_t* rowptr,
-                                      const int32_t* col,
-                              const int32_t* blockPartition, const int32_t* edgeToColumn, const int32_t* edgeToRow,
-                              const int32_t* hybrid_type, const int32_t* plan_d, const hcspmm_plan_header* ph,
-                              int64_t N, int64_t E, int D, void* workspace, size_t workspace_bytes, void* stream_v) {
+extern "C" int hcspmm_forward_typed(const void* X, int64_t ldx, void* Z, int64_t ldz, int dtype, const int32_t* rowptr,
+                                    const int32_t* col, const int32_t* blockPartition, const int32_t* edgeToColumn,
+                                    const int32_t* edgeToRow, const int32_t* hybrid_type, const int32_t* plan_d,
+                                    const hcspmm_plan_header* ph, int64_t N, int64_t E, int D, void* workspace,
+                                    size_t workspace_bytes, void* stream_v) {
+  if (dtype < HCSPMM_DTYPE_F32 || dtype > HCSPMM_DTYPE_BF16) return HCSPMM_EINVAL;
   if (N < 0 || E < 0 || D <= 0 || ldx < D || ldz < D) return HCSPMM_EINVAL;
   if (N == 0) return HCSPMM_OK;
   if (!X || !Z || !rowptr || (E > 0 && !col)) return HCSPMM_EINVAL;
@@ -136,7 +153,7 @@ extern "C" int hcspmm_forward_strided(const float* X, int64_t ldx, float* Z, int
     a.n_dense_compact = ph->n_dense_compact;
     a.off_fixups = ph->off_fixups;
     a.n_split_rows = ph->n_split_rows;
-    wide_choice(ph, D, &a.n_wide, &a.panel_cols);
+    wide_choice(ph, D, dtype, &a.n_wide, &a.panel_cols);
     a.sparse_wgs_pp = 0;
     a.dense_vec = 0;
     a.wide_wgs = 0;
@@ -144,7 +161,10 @@ extern "C" int hcspmm_forward_strided(const float* X, int64_t ldx, float* Z, int
     a.D = D;
     a.sparse_wgs = 0;
     a.n_panels = 0;
-    e = hcspmm::launch_plan(a, pick_vec(D, ldx, ldz, X, Z, need ? workspace : nullptr), stream);
+    const int vec = pick_vec(dtype, D, ldx, ldz, X, Z, need ? workspace : nullptr);
+    e = dtype == HCSPMM_DTYPE_F32 ? hcspmm::launch_plan_f32(a, vec, stream)
+        : dtype == HCSPMM_DTYPE_F16 ? hcspmm::launch_plan_f16(a, vec, stream)
+                                    : hcspmm::launch_plan_bf16(a, vec, stream);
   } else {
     if (plan_d || ph) return HCSPMM_EINVAL;  // both or neither
     if (!blockPartition || !hybrid_type || (E > 0 && (!edgeToColumn || !edgeToRow))) return HCSPMM_EINVAL;
@@ -161,9 +181,21 @@ extern "C" int hcspmm_forward_strided(const float* X, int64_t ldx, float* Z, int
     a.hybrid_type = hybrid_type;
     a.N = (int)N;
     a.D = D;
-    e = hcspmm::launch_window(a, pick_vec(D, ldx, ldz, X, Z, nullptr), stream);
+    const int vec = pick_vec(dtype, D, ldx, ldz, X, Z, nullptr);
+    e = dtype == HCSPMM_DTYPE_F32 ? hcspmm::launch_window_f32(a, vec, stream)
+        : dtype == HCSPMM_DTYPE_F16 ? hcspmm::launch_window_f16(a, vec, stream)
+                                    : hcspmm::launch_window_bf16(a, vec, stream);
   }
   return e == hipSuccess ? HCSPMM_OK : fail_hip(e);
+}
+
+extern "C" int hcspmm_forward_strided(const float* X, int64_t ldx, float* Z, int64_t ldz, const int32_t* rowptr,
+                                      const int32_t* col, const int32_t* blockPartition, const int32_t* edgeToColumn,
+                                      const int32_t* edgeToRow, const int32_t* hybrid_type, const int32_t* plan_d,
+                                      const hcspmm_plan_header* ph, int64_t N, int64_t E, int D, void* workspace,
+                                      size_t workspace_bytes, void* stream_v) {
+  return hcspmm_forward_typed(X, ldx, Z, ldz, HCSPMM_DTYPE_F32, rowptr, col, blockPartition, edgeToColumn, edgeToRow,
+                              hybrid_type, plan_d, ph, N, E, D, workspace, workspace_bytes, stream_v);
 }
 
 extern "C" int hcspmm_forward(const float* X, float* Z, const int32_t* rowptr, const int32_t* col,

@@ -27,16 +27,19 @@ inline int classify(int32_t size, uint32_t nnz, int32_t num, int rule) {
   const double logit = (t1 - t2) - 3.14922857;
   if (rule == HCSPMM_RULE_MI355X || rule == HCSPMM_RULE_MI355X_WIDE) {
     // refit on MI355X against this library's two sub-paths (tools/refit_classifier.py, 65536 windows,
-    // profiles/r01/classifier_refit_v2.json).  The boundary depends on the embedding width -- at D = 32 the
-    // sparse-row path (tiny tasks, 16-byte gathers) wins below ~25 % tile density, at D = 128 the dense-tile
-    // path wins for every window of more than two columns -- so there is one coefficient set per width
-    // class: z = w1*size + w2*density + b, sparse-row path when z > 0.  The narrow fit uses the density alone:
-    // its unconstrained w1 came out slightly negative (noise: the boundary sits at ~0.2 density for every K
-    // measured), which extrapolated hub windows of thousands of columns onto the dense-tile path.
+    // profiles/r01/classifier_refit_v3.json):  z = w1*size + w2*density + b, sparse-row path when z > 0.
+    // The boundary depends on the embedding width (at D = 32 the sparse-row path wins below 10-20 % tile
+    // density, at D = 128 the dense-tile path wins almost everywhere) and on whether the window gets a compact
+    // record (at most 32 padded columns: two round trips per unit instead of three), so there is one
+    // coefficient set per (width class, record kind).  Three sets use the density alone: their free fits had a
+    // slightly negative w1 (noise inside K <= 130) that extrapolated hub windows onto the dense-tile path.
     const bool wide = rule == HCSPMM_RULE_MI355X_WIDE;
-    const double w1 = wide ? 0.030703533058157952 : 0.0;
-    const double w2 = wide ? -139.72170588602881 : -27.50482224598512;
-    const double b = wide ? 4.259271957775277 : 6.198636370393027;
+    const bool compact = num * HCSPMM_BLK_W <= HCSPMM_COMPACT_K;
+    double w1 = 0.0, w2, b;
+    if (!wide && compact) { w2 = -30.904771063924702; b = 3.2248272656712498; }
+    else if (!wide) { w2 = -91.39571130769644; b = 18.406719120321213; }
+    else if (compact) { w2 = -39.36167079949795; b = -0.21260854261350828; }
+    else { w1 = 0.08953178072727347; w2 = -46.44063869582706; b = -6.402170211696355; }
     const double z = ((double)((float)size) * w1 + (double)dens * w2) + b;
     return z > 0 ? 0 : 1;
   }

@@ -1,0 +1,735 @@
+// spmm_impl.h -- gfx950 (MI355X, CDNA4) device code of the hybrid SpMM  Z = A * X, templated on the
+// feature element type (fp32; fp16 / bf16 features with fp32 accumulation -- paper p.16 Table VII).
+// Included by spmm_kernels.hip (fp32 instantiations) and spmm_kernels_h16.hip (16-bit ones).
+//
+// Replaces the reference kernels spmm_forward_cuda_kernel_arbi_warps_hybrid_{adaptive,32,64,
+// adaptive_more} (hybrid_kernel/hybrid_all_kernel.cu:919-1637).  Nothing here is derived from
+// their structure: the reference runs one 96-thread block per 16-row window with warp-per-row
+// gathers and WMMA tf32 tiles staged through shared memory; this file is wave64 code built
+// around two facts of the machine (see /DESIGN.md):
+//
+//  * sparse-row path: the launch is bound by the gathered X-row bytes that miss the per-XCD L2, so
+//    (a) rows become *tasks* ordered by power-of-two length class (host plan); L lanes of a wave own
+//    one task and walk its neighbours strictly in CSR order (bit-identical to a sequential fp32
+//    sum), 64/L tasks share a wave; the longest tasks go to whole waves ("wide", shuffle-tree
+//    combine); (b) wide embeddings are processed panel-major, one cache line (128 bytes) per row
+//    at a time across the whole grid; (c) column indices are fetched coalesced once per L
+//    neighbours and broadcast through the LDS crossbar (ds_bpermute); every lane issues 16-byte
+//    loads in branch-free batches of 8.
+//  * dense-tile path: v_mfma_f32_16x16x4_f32 takes its B operand one fp32 per lane, so the
+//    gathered X rows go from HBM straight into MFMA operand registers with 16-byte loads (the
+//    VEC elements of a lane feed VEC MFMAs whose results re-assemble into one vector store);
+//    the 0/1 tile of A arrives as a 64-bit lane mask per k-step, packed by the host in MFMA
+//    lane order.  No LDS round trip, no barrier.  fp32 MFMA is an exact k-ordered fma chain,
+//    so the result equals the sequential sum over the window's ascending unique columns.
+//
+// 16-bit features: rows are gathered as they are stored (half the bytes), widened to fp32 in
+// registers (exact), summed in fp32 in the same order as the fp32 path, and rounded once (RNE) when
+// the row is stored.  The dense-tile path keeps the fp32 MFMA (the 16-bit MFMAs want four k-values
+// of one column per lane -- a transposed gather).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hcspmm.h"
+#include "spmm_kernels.h"
+
+namespace hcspmm {
+
+// ---------------------------------------------------------------- element types and lane vectors
+struct F32 { typedef float T; };
+struct F16 { typedef unsigned short T; };   // IEEE binary16 bits
+struct BF16 { typedef unsigned short T; };  // bfloat16 bits
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// fp32 accumulator of VEC feature columns
+template <int VEC> struct AccT { typedef float type __attribute__((ext_vector_type(VEC))); };
+template <> struct AccT<1> { typedef float type; };
+__device__ __forceinline__ float aget(const float& v, int) { return v; }
+__device__ __forceinline__ void aset(float& v, int, float x) { v = x; }
+template <typename V> __device__ __forceinline__ float aget(const V& v, int i) { return v[i]; }
+template <typename V> __device__ __forceinline__ void aset(V& v, int i, float x) { v[i] = x; }
+template <int VEC> __device__ __forceinline__ typename AccT<VEC>::type azero() {
+  typename AccT<VEC>::type z;
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) aset(z, q, 0.f);
+  return z;
+}
+
+// VEC elements as they sit in memory
+template <typename E, int VEC> struct RawT { typedef typename AccT<VEC>::type type; };  // F32: the floats themselves
+template <> struct RawT<F16, 8> { typedef u32x4 type; };
+template <> struct RawT<F16, 4> { typedef u32x2 type; };
+template <> struct RawT<F16, 2> { typedef unsigned int type; };
+template <> struct RawT<F16, 1> { typedef unsigned short type; };
+template <> struct RawT<BF16, 8> { typedef u32x4 type; };
+template <> struct RawT<BF16, 4> { typedef u32x2 type; };
+template <> struct RawT<BF16, 2> { typedef unsigned int type; };
+template <> struct RawT<BF16, 1> { typedef unsigned short type; };
+
+template <typename E> __device__ __forceinline__ float widen(unsigned short h);
+template <> __device__ __forceinline__ float widen<F16>(unsigned short h) { return (float)__builtin_bit_cast(_Float16, h); }
+template <> __device__ __forceinline__ float widen<BF16>(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+template <typename E> __device__ __forceinline__ unsigned short narrow(float f);
+template <> __device__ __forceinline__ unsigned short narrow<F16>(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
+template <> __device__ __forceinline__ unsigned short narrow<BF16>(float f) {  // round to nearest even
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);  // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+__device__ __forceinline__ unsigned rword(const u32x4& v, int i) { return v[i]; }
+__device__ __forceinline__ unsigned rword(const u32x2& v, int i) { return v[i]; }
+__device__ __forceinline__ unsigned rword(const unsigned& v, int) { return v; }
+__device__ __forceinline__ void rset(u32x4& v, int i, unsigned w) { v[i] = w; }
+__device__ __forceinline__ void rset(u32x2& v, int i, unsigned w) { v[i] = w; }
+__device__ __forceinline__ void rset(unsigned& v, int, unsigned w) { v = w; }
+
+template <typename E, int VEC> struct Lane {
+  typedef typename E::T T;
+  typedef typename RawT<E, VEC>::type raw_t;
+  typedef typename AccT<VEC>::type acc_t;
+  static __device__ __forceinline__ raw_t zero() {
+    raw_t z;
+    __builtin_memset(&z, 0, sizeof(z));
+    return z;
+  }
+  static __device__ __forceinline__ raw_t load(const T* p) { return *reinterpret_cast<const raw_t*>(p); }
+  // element q of a loaded vector, widened (exact)
+  static __device__ __forceinline__ float elem(const raw_t& v, int q) {
+    if constexpr (sizeof(T) == 4) return aget(v, q);
+    else if constexpr (VEC == 1) return widen<E>(v);
+    else {
+      const unsigned w = rword(v, q >> 1);
+      return widen<E>((unsigned short)((q & 1) ? (w >> 16) : (w & 0xffffu)));
+    }
+  }
+  static __device__ __forceinline__ void add(acc_t& acc, const raw_t& v) {
+    if constexpr (sizeof(T) == 4) acc += v;
+    else {
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) aset(acc, q, aget(acc, q) + elem(v, q));
+    }
+  }
+  static __device__ __forceinline__ raw_t pack(const acc_t& acc) {  // one rounding per element (16-bit types)
+    if constexpr (sizeof(T) == 4) return acc;
+    else if constexpr (VEC == 1) return narrow<E>(acc);
+    else {
+      raw_t r;
+#pragma unroll
+      for (int w = 0; w < VEC / 2; ++w)
+        rset(r, w, (unsigned)narrow<E>(aget(acc, 2 * w)) | ((unsigned)narrow<E>(aget(acc, 2 * w + 1)) << 16));
+      return r;
+    }
+  }
+  // Z rows are written once and not re-read by this launch: non-temporal stores (0-5 %, profiles/r01/ab_nt_store.log)
+  static __device__ __forceinline__ void store(T* p, const acc_t& acc) {
+    __builtin_nontemporal_store(pack(acc), reinterpret_cast<raw_t*>(p));
+  }
+  static __device__ __forceinline__ void store_partial(float* p, const acc_t& acc) {
+    __builtin_nontemporal_store(acc, reinterpret_cast<acc_t*>(p));
+  }
+};
+
+constexpr int kWaves = 4;            // waves per workgroup (256 threads)
+constexpr int kThreads = kWaves * 64;
+#ifndef HCSPMM_SPARSE_U
+#define HCSPMM_SPARSE_U 8  // row loads in flight per lane on the sparse-row path
+#endif
+#ifndef HCSPMM_DENSE_B
+#define HCSPMM_DENSE_B 8   // k-steps (16-byte row loads in flight per lane) per batch on the dense-tile path
+#endif
+#ifndef HCSPMM_TINY_PER_WAVE
+#define HCSPMM_TINY_PER_WAVE 8  // tiny tasks (<= 2 entries) per wave: T = 8 / (64/L) per lane group, at least 2, at most 4
+#endif                          // (D = 32: T = 2 vs 4 vs 8 in profiles/r01/ab_tiny_tasks.log; wide D: ab_tiny_tasks_wide.log;
+                                //  T = 8 costs the L = 32 build its fifth wave per SIMD: 119 instead of 94 registers)
+template <int L> struct TinyT {
+  static constexpr int per_group = HCSPMM_TINY_PER_WAVE / (64 / L);
+  static constexpr int value = per_group < 2 ? 2 : (per_group > 4 ? 4 : per_group);
+};
+#ifndef HCSPMM_MIN_WAVES_PER_SIMD
+#define HCSPMM_MIN_WAVES_PER_SIMD 4  // <= 128 registers per lane (measured best with U = B = 8: profiles/r01/ab_u_b_mw_v2.log)
+#endif
+
+// One branch-free batch of UB row gathers: every lane issues all UB loads (finished tasks and lanes
+// beyond the embedding width re-read row 0 / column 0, an L1 hit, and discard it), so the batch is one
+// basic block -- UB broadcasts, UB address computations, UB loads back to back, counted waits.
+// (Staging the rows through LDS instead was built and measured -- never faster, +9 % at D = 32:
+// profiles/r01/ab_lds_stage.log, code at commit 950912e.)
+template <typename E, int VEC, int UB>
+__device__ __forceinline__ void gather_batch(const typename E::T* __restrict__ X, size_t ldx, int csafe, bool cok,
+                                             int myidx, int src0, typename AccT<VEC>::type& acc,
+                                             const int* prefetch_from, int& prefetched) {
+  typedef Lane<E, VEC> Ln;
+  int idx[UB];
+  typename Ln::raw_t v[UB];
+#pragma unroll
+  for (int u = 0; u < UB; ++u) idx[u] = __shfl(myidx, src0 + u, 64);
+  // the next chunk's indices are requested here -- after this chunk's were broadcast, ahead of its row
+  // loads -- so they arrive under those loads and a chunk costs one round trip, not two
+  if (prefetch_from != nullptr) prefetched = *prefetch_from;
+#pragma unroll
+  for (int u = 0; u < UB; ++u) v[u] = Ln::load(X + (size_t)max(idx[u], 0) * ldx + csafe);
+#pragma unroll
+  for (int u = 0; u < UB; ++u) {
+    if (!(cok && idx[u] >= 0)) v[u] = Ln::zero();
+    Ln::add(acc, v[u]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Sparse-row task body: the L lanes [lane & ~(L-1), +L) own one task (row or row segment)
+// = CSR entries [e0, e0 + n); lane slot s covers columns pbase + s*VEC .. +VEC.  All control
+// flow is wave-uniform (loop bounds come from the wave-wide maximum n); shorter tasks are
+// predicated off by idx = -1, and adding the resulting 0.0f is exact.  The result goes to
+// dstZ (a row of Z, element type) or dstP (a partial-sum row of the fp32 workspace).
+// ------------------------------------------------------------------------------------------
+template <typename E, int L, int VEC, bool WIDE, int UMAX = HCSPMM_SPARSE_U>
+__device__ __forceinline__ void sparse_task(const typename E::T* __restrict__ X, typename E::T* __restrict__ dstZ,
+                                            float* __restrict__ dstP, const int* __restrict__ col, int e0, int n,
+                                            size_t ldx, int c0, int cend, int lane) {
+  typedef Lane<E, VEC> Ln;
+  typedef typename Ln::acc_t acc_t;
+  constexpr int U = (L < UMAX) ? L : UMAX;  // loads in flight per lane
+  // WIDE: the whole wave owns ONE task (e0, n wave-uniform); per 64-entry super-chunk lane i holds
+  // entry base+i, so lane group g sums entries [base + g*L, base + (g+1)*L) and the 64/L group sums
+  // are combined by a fixed xor-shuffle tree at the end.  Otherwise each lane group owns its own task.
+  constexpr int STRIDE = WIDE ? 64 : L;
+  const int s = lane & (L - 1);
+  const int pos = WIDE ? lane : s;
+  const int gbase = lane & ~(L - 1);
+  int nmax = n;
+  if (!WIDE) {
+#pragma unroll
+    for (int off = L; off < 64; off <<= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
+  }
+  nmax = __builtin_amdgcn_readfirstlane(nmax);
+
+  for (int pbase = c0; pbase < cend; pbase += L * VEC) {  // feature columns [c0, cend) of the rows
+    const int c = pbase + s * VEC;
+    const bool cok = c < cend;
+    const int csafe = cok ? c : 0;
+    acc_t acc = azero<VEC>();
+    int next = (pos < n) ? col[e0 + pos] : -1;
+    for (int base = 0; base < nmax; base += STRIDE) {
+      const int myidx = next;
+      const bool more = base + STRIDE + pos < n;
+      next = -1;
+      const int cnt = min(L, nmax - base);  // longest lane group's share of this chunk
+      const int* pf = more ? col + e0 + base + STRIDE + pos : nullptr;  // consumed by the chunk's first batch
+      for (int j = 0; j < cnt;) {
+        const int left = cnt - j;  // wave-uniform: short tasks (the bulk of a low-degree graph) get
+        if (left > U / 2) {        // short batches instead of a full one padded with dummy loads
+          gather_batch<E, VEC, U>(X, ldx, csafe, cok, myidx, gbase + j, acc, pf, next);
+          j += U;
+        } else if (U >= 8 && left > U / 4) {
+          gather_batch<E, VEC, (U >= 8 ? U / 2 : 1)>(X, ldx, csafe, cok, myidx, gbase + j, acc, pf, next);
+          j += U / 2;
+        } else if (U >= 4 && left > 1) {
+          gather_batch<E, VEC, (U >= 8 ? U / 4 : 2)>(X, ldx, csafe, cok, myidx, gbase + j, acc, pf, next);
+          j += (U >= 8 ? U / 4 : 2);
+        } else {
+          gather_batch<E, VEC, 1>(X, ldx, csafe, cok, myidx, gbase + j, acc, pf, next);
+          j += 1;
+        }
+        pf = nullptr;
+      }
+    }
+    if (WIDE) {
+#pragma unroll
+      for (int off = L; off < 64; off <<= 1) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) aset(acc, q, aget(acc, q) + __shfl_xor(aget(acc, q), off, 64));
+      }
+    }
+    if (cok && (!WIDE || lane < L)) {
+      if (dstZ != nullptr) Ln::store(dstZ + c, acc);
+      else if (dstP != nullptr) Ln::store_partial(dstP + c, acc);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Tiny tasks (at most two entries, indices inline in the descriptor: hcspmm.h n_tiny).  On a low-degree
+// graph these are most of the rows, and a wave that handles 64/L of them is a chain of dependent round
+// trips (descriptor -> indices -> rows -> store) with one or two loads in flight per lane: latency, not
+// bandwidth, sets the time (tools/lowdeg_breakdown.py).  Here each lane group takes T tasks at once: T
+// independent descriptor loads, then up to 2T independent row loads, then T stores -- two round trips
+// per T tasks.  The sum is 0 + x[index0] + x[index1] in that order: the sequential CSR order.
+// ------------------------------------------------------------------------------------------
+template <typename E, int L, int VEC, int T>
+__device__ __forceinline__ void tiny_tasks(const PlanArgs& a, int first, int c0, int cend, int lane) {
+  typedef Lane<E, VEC> Ln;
+  typedef typename E::T elem_t;
+  const elem_t* X = reinterpret_cast<const elem_t*>(a.X);
+  elem_t* Z = reinterpret_cast<elem_t*>(a.Z);
+  constexpr int R = 64 / L;
+  const int g = lane / L, s = lane & (L - 1);
+  const int4* tasks = reinterpret_cast<const int4*>(a.plan + a.off_tasks);
+  int4 d[T];
+  bool any1 = false, any2 = false;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int tid = first + t * R + g;  // consecutive tasks (= ascending rows) across the lane groups
+    d[t] = (tid < a.n_tasks) ? tasks[tid] : int4{0, -1, -1, -1};  // .z < 0: no task
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    any1 |= d[t].y >= 0;
+    any2 |= d[t].w >= 0;
+  }
+  any1 = __builtin_amdgcn_ballot_w64(any1) != 0;  // wave-uniform: a wave inside the 0- or 1-entry class issues
+  any2 = __builtin_amdgcn_ballot_w64(any2) != 0;  // no loads for the absent entries
+  for (int pbase = c0; pbase < cend; pbase += L * VEC) {
+    const int c = pbase + s * VEC;
+    const bool cok = c < cend;
+    const int csafe = cok ? c : 0;
+    typename Ln::raw_t v0[T], v1[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) v0[t] = v1[t] = Ln::zero();
+    if (any1) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) v0[t] = Ln::load(X + (size_t)max(d[t].y, 0) * a.ldx + csafe);
+    }
+    if (any2) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) v1[t] = Ln::load(X + (size_t)max(d[t].w, 0) * a.ldx + csafe);
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      typename Ln::acc_t acc = azero<VEC>();
+      if (d[t].y >= 0) Ln::add(acc, v0[t]);
+      if (d[t].w >= 0) Ln::add(acc, v1[t]);
+      if (cok && d[t].z >= 0) {
+        if (d[t].x >= 0) Ln::store(Z + (size_t)d[t].x * a.ldz + c, acc);
+        else Ln::store_partial(a.partial + (size_t)(-(d[t].x + 1)) * (size_t)a.D + c, acc);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Dense-tile unit: one wave = (dense window, panel of 16*VEC feature columns).
+// MFMA operand maps (v_mfma_f32_16x16x4_f32): lane l supplies A[i = l & 15][k = l >> 4] and
+// B[k = l >> 4][j = l & 15]; accumulator register r of lane l is D[4*(l >> 4) + r][l & 15].
+// Instruction q of a k-step multiplies by feature column  panel + j*VEC + q, so after the VEC
+// instructions lane l holds Z[row 4*(l>>4)+r][panel + j*VEC .. +VEC) -- a contiguous vector.
+// ------------------------------------------------------------------------------------------
+template <typename E, int VEC>
+__device__ __forceinline__ void dense_store(typename E::T* __restrict__ Z, const f32x4 (&acc)[VEC], int window, int kq,
+                                            int c, int N, size_t ldz) {
+  typedef Lane<E, VEC> Ln;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = window * 16 + 4 * kq + r;
+    if (row < N) {
+      typename Ln::acc_t o;
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) aset(o, q, acc[q][r]);
+      Ln::store(Z + (size_t)row * ldz + c, o);
+    }
+  }
+}
+
+template <typename E, int VEC>
+__device__ __forceinline__ void dense_unit(const typename E::T* __restrict__ X, typename E::T* __restrict__ Z,
+                                           const int* __restrict__ U, const unsigned long long* __restrict__ masks,
+                                           int K4, int window, int panel, int N, int D, size_t ldx, size_t ldz,
+                                           int lane) {
+  typedef Lane<E, VEC> Ln;
+  const int kq = lane >> 4, j = lane & 15;
+  const int c = panel * 16 * VEC + j * VEC;
+  const bool cok = c < D;
+  const int csafe = cok ? c : 0;
+  f32x4 acc[VEC];
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int kb = 0; kb < K4; kb += 16) {
+    const int myU = (kb * 4 + lane < K4 * 4) ? U[kb * 4 + lane] : -1;
+    const int steps = min(16, K4 - kb);
+    // same bytes in flight per lane whatever the panel width
+    constexpr int B = HCSPMM_DENSE_B * 16 / (VEC * (int)sizeof(typename E::T));
+    for (int t0 = 0; t0 < steps; t0 += B) {
+      // Branch-free batch (see sparse_task): padded columns (U = -1) and steps past the end re-read
+      // row 0 and are zeroed by the select; their A tile is zero as well.
+      int idx[B];
+      typename Ln::raw_t x[B];
+      float a[B];
+#pragma unroll
+      for (int u = 0; u < B; ++u) {
+        const int t = t0 + u;
+        idx[u] = __shfl(myU, (4 * t + kq) & 63, 64);
+        const unsigned long long m = masks[min(kb + t, K4 - 1)];  // wave-uniform address: scalar load
+        a[u] = (t < steps && ((m >> lane) & 1ull)) ? 1.0f : 0.0f;
+        if (t >= steps) idx[u] = -1;
+      }
+#pragma unroll
+      for (int u = 0; u < B; ++u) x[u] = Ln::load(X + (size_t)max(idx[u], 0) * ldx + csafe);
+#pragma unroll
+      for (int u = 0; u < B; ++u) {
+        if (!(cok && idx[u] >= 0)) x[u] = Ln::zero();
+        if (t0 + u < steps) {  // wave-uniform: no MFMA issue slots for the padding of a short batch
+#pragma unroll
+          for (int q = 0; q < VEC; ++q)
+            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], Ln::elem(x[u], q), acc[q], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (cok) dense_store<E, VEC>(Z, acc, window, kq, c, N, ldz);
+}
+
+// Compact dense unit: a window of at most 32 (padded) columns whose whole description is one 64-word
+// record at an address that follows from the unit number (hcspmm.h n_dense_compact): lane l loads word l
+// -- one coalesced 256-byte load -- and the wave can gather: window / K4 / masks go to scalar registers
+// (v_readlane), the column list is broadcast as in dense_unit.  Two round trips per unit instead of three.
+// Same MFMA chain as dense_unit, so the same bits.
+template <typename E, int VEC, int STEPS>
+__device__ __forceinline__ void compact_steps(const typename E::T* __restrict__ X, int word, int K4, int csafe,
+                                              bool cok, size_t ldx, int lane, f32x4 (&acc)[VEC]) {
+  typedef Lane<E, VEC> Ln;
+  const int kq = lane >> 4;
+  int idx[STEPS];
+  typename Ln::raw_t x[STEPS];
+  float a[STEPS];
+#pragma unroll
+  for (int t = 0; t < STEPS; ++t) {
+    idx[t] = __shfl(word, 2 + 4 * t + kq, 64);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane(word, 2 + HCSPMM_COMPACT_K + 2 * t);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane(word, 3 + HCSPMM_COMPACT_K + 2 * t);
+    const unsigned long long m = ((unsigned long long)hi << 32) | lo;
+    a[t] = (t < K4 && ((m >> lane) & 1ull)) ? 1.0f : 0.0f;
+    if (t >= K4) idx[t] = -1;
+  }
+#pragma unroll
+  for (int t = 0; t < STEPS; ++t) x[t] = Ln::load(X + (size_t)max(idx[t], 0) * ldx + csafe);
+#pragma unroll
+  for (int t = 0; t < STEPS; ++t) {
+    if (!(cok && idx[t] >= 0)) x[t] = Ln::zero();
+    if (t < K4) {  // wave-uniform
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], Ln::elem(x[t], q), acc[q], 0, 0, 0);
+    }
+  }
+}
+
+template <typename E, int VEC>
+__device__ __forceinline__ void dense_compact_unit(const typename E::T* __restrict__ X, typename E::T* __restrict__ Z,
+                                                   const int* __restrict__ rec, int panel, int N, int D, size_t ldx,
+                                                   size_t ldz, int lane) {
+  const int word = rec[lane];
+  const int window = __builtin_amdgcn_readlane(word, 0);
+  const int K4 = __builtin_amdgcn_readlane(word, 1);
+  const int kq = lane >> 4, j = lane & 15;
+  const int c = panel * 16 * VEC + j * VEC;
+  const bool cok = c < D;
+  const int csafe = cok ? c : 0;
+  f32x4 acc[VEC];
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (K4 <= 2) compact_steps<E, VEC, 2>(X, word, K4, csafe, cok, ldx, lane, acc);
+  else if (K4 <= 4) compact_steps<E, VEC, 4>(X, word, K4, csafe, cok, ldx, lane, acc);
+  else compact_steps<E, VEC, 8>(X, word, K4, csafe, cok, ldx, lane, acc);
+  if (cok) dense_store<E, VEC>(Z, acc, window, kq, c, N, ldz);
+}
+
+// ------------------------------------------------------------------------------------------
+// Planned hybrid kernel: ONE launch covers both sub-paths (as the reference's single launch
+// does, K.cu:960/1039) -- per column panel, workgroups [0, wide_wgs) run wide sparse tasks, then ordinary
+// ones, then tiny ones (the last tiny_wgs); after all sparse panels come the dense units.
+// ------------------------------------------------------------------------------------------
+// UNROLL row loads in flight per lane, MINW waves per SIMD the register budget must allow.  With the
+// branch-free batches <8, 4> is best for throughput- and latency-bound launches alike
+// (profiles/r01/ab_u_b_mw_v2.log; before them <4, 8> won: profiles/r01/ab_u_b_mw.log).
+__device__ __forceinline__ int sparse_wgs_pp_ordinary_end(const PlanArgs& a) { return a.sparse_wgs_pp - a.tiny_wgs; }
+
+// second-widest and narrowest dense-tile vector of a VEC-wide build
+template <int VEC> struct DenseV {
+  static constexpr int mid = VEC >= 8 ? 4 : (VEC >= 4 ? 2 : 1);  // fp32: 4 -> 2; 16-bit: 8 -> 4
+};
+
+template <typename E, int L, int VEC, int UNROLL, int MINW>
+__global__ __launch_bounds__(kThreads, MINW) void hybrid_plan_kernel(PlanArgs a) {
+  typedef typename E::T elem_t;
+  const elem_t* X = reinterpret_cast<const elem_t*>(a.X);
+  elem_t* Z = reinterpret_cast<elem_t*>(a.Z);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if ((int)blockIdx.x < a.sparse_wgs) {
+    // column-panel-major: every sparse task runs once per panel of a.panel_cols feature columns, and
+    // all workgroups of panel p precede those of panel p+1, so at any time the gathers touch one
+    // 128-byte slice of the X rows -- four times as many distinct rows fit the per-XCD L2
+    const int p = (int)blockIdx.x / a.sparse_wgs_pp;
+    const int b = (int)blockIdx.x - p * a.sparse_wgs_pp;
+    const int c0 = p * a.panel_cols;
+    const int cend = min(a.D, c0 + a.panel_cols);
+    if (b < a.wide_wgs) {
+      // wide tasks: the a.n_wide longest tasks, one per wave
+      const int tid = b * kWaves + wave;
+      if (tid >= a.n_wide) return;
+      const int4 t = reinterpret_cast<const int4*>(a.plan + a.off_tasks)[tid];
+      elem_t* dz = (t.w < 0) ? Z + (size_t)t.x * a.ldz : nullptr;
+      float* dp = (t.w < 0) ? nullptr : a.partial + (size_t)t.w * (size_t)a.D;
+      sparse_task<E, L, VEC, true, UNROLL>(X, dz, dp, a.col, __builtin_amdgcn_readfirstlane(t.y),
+                                           __builtin_amdgcn_readfirstlane(t.z), a.ldx, c0, cend, lane);
+    } else if (b >= sparse_wgs_pp_ordinary_end(a)) {
+      constexpr int R = 64 / L;
+      const int first = a.n_tasks - a.n_tiny + ((b - sparse_wgs_pp_ordinary_end(a)) * kWaves + wave) * (R * TinyT<L>::value);
+      if (first >= a.n_tasks) return;
+      tiny_tasks<E, L, VEC, TinyT<L>::value>(a, first, c0, cend, lane);
+    } else {
+      constexpr int R = 64 / L;
+      const int g = lane / L;
+      const int tid = a.n_wide + ((b - a.wide_wgs) * kWaves + wave) * R + g;
+      int e0 = 0, n = 0;
+      elem_t* dz = nullptr;
+      float* dp = nullptr;
+      if (tid < a.n_tasks - a.n_tiny) {
+        const int4 t = reinterpret_cast<const int4*>(a.plan + a.off_tasks)[tid];
+        e0 = t.y;
+        n = t.z;
+        if (t.w < 0) dz = Z + (size_t)t.x * a.ldz;
+        else dp = a.partial + (size_t)t.w * (size_t)a.D;
+      }
+      sparse_task<E, L, VEC, false, UNROLL>(X, dz, dp, a.col, e0, n, a.ldx, c0, cend, lane);
+    }
+  } else {
+    constexpr int VM = DenseV<VEC>::mid;
+    int unit = ((int)blockIdx.x - a.sparse_wgs) * kWaves + wave;
+    if (unit >= a.n_dense * a.n_panels) return;
+    const int n_reg = a.n_dense - a.n_dense_compact;  // regular windows (K > 32) first, widest first
+    if (unit >= n_reg * a.n_panels) {
+      unit -= n_reg * a.n_panels;
+      const int panel = unit / a.n_dense_compact, ci = unit - panel * a.n_dense_compact;  // panel-major
+      const int* rec = a.plan + a.off_dense_compact + ci * HCSPMM_COMPACT_WORDS;
+      // elements per lane on the dense-tile path (a panel is 16*dense_vec columns): set by the launcher from D
+      if (a.dense_vec == VEC) dense_compact_unit<E, VEC>(X, Z, rec, panel, a.N, a.D, a.ldx, a.ldz, lane);
+      else if (a.dense_vec == VM) dense_compact_unit<E, VM>(X, Z, rec, panel, a.N, a.D, a.ldx, a.ldz, lane);
+      else dense_compact_unit<E, 1>(X, Z, rec, panel, a.N, a.D, a.ldx, a.ldz, lane);
+      return;
+    }
+    const int panel = unit / n_reg, di = unit - panel * n_reg;  // panel-major, like the sparse region
+    const int4 d = reinterpret_cast<const int4*>(a.plan + a.off_dense_index)[di];
+    const int* U = a.plan + a.off_dense_pack + d.y;
+    const unsigned long long* masks = reinterpret_cast<const unsigned long long*>(U + 4 * d.z);
+    if (a.dense_vec == VEC) dense_unit<E, VEC>(X, Z, U, masks, d.z, d.x, panel, a.N, a.D, a.ldx, a.ldz, lane);
+    else if (a.dense_vec == VM) dense_unit<E, VM>(X, Z, U, masks, d.z, d.x, panel, a.N, a.D, a.ldx, a.ldz, lane);
+    else dense_unit<E, 1>(X, Z, U, masks, d.z, d.x, panel, a.N, a.D, a.ldx, a.ldz, lane);
+  }
+}
+
+// Fix-up: rows that were split into segments -- Z[row] = partial[s0] + partial[s0+1] + ... in
+// segment order (deterministic).  One wave per split row.  Partials are fp32 whatever the feature type.
+template <typename E, int VEC>
+__global__ __launch_bounds__(kThreads) void fixup_kernel(PlanArgs a) {
+  typedef Lane<E, VEC> Ln;
+  typedef typename Ln::acc_t acc_t;
+  typename E::T* Z = reinterpret_cast<typename E::T*>(a.Z);
+  const int lane = threadIdx.x & 63;
+  const int fi = (int)blockIdx.x * kWaves + (threadIdx.x >> 6);
+  if (fi >= a.n_split_rows) return;
+  const int4 f = reinterpret_cast<const int4*>(a.plan + a.off_fixups)[fi];
+  const int row = f.x, s0 = f.y, ns = f.z;
+  for (int c = lane * VEC; c < a.D; c += 64 * VEC) {
+    const float* p = a.partial + (size_t)s0 * (size_t)a.D + c;
+    acc_t acc = *reinterpret_cast<const acc_t*>(p);
+    int s = 1;
+    for (; s + 4 <= ns; s += 4) {  // four independent loads in flight, added in segment order
+      acc_t v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const acc_t*>(p + (size_t)(s + u) * (size_t)a.D);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc += v[u];
+    }
+    for (; s < ns; ++s) acc += *reinterpret_cast<const acc_t*>(p + (size_t)s * (size_t)a.D);
+    Ln::store(Z + (size_t)row * a.ldz + c, acc);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Plan-free kernel (callers that pass the reference's [0] placeholders): one workgroup per
+// 16-row window, branch on hybrid_type[window] exactly like the reference launch.  Sparse
+// windows deal their rows to the workgroup's lane groups; dense windows rebuild the window's
+// unique-column list and tile masks in LDS from edgeToColumn / edgeToRow / column_index (the
+// reference builds sparse_A / sparse_AToX_index the same way, K.cu:1067-1074) in chunks of
+// kChunkK condensed columns, so any blockPartition is handled.
+// ------------------------------------------------------------------------------------------
+constexpr int kChunkK = 512;  // condensed columns per LDS pass (128 k-steps)
+constexpr int kPlanFreeWide = 64;  // plan-free kernel: rows longer than this are summed by a whole wave
+
+template <typename E, int L, int VEC>
+__global__ __launch_bounds__(kThreads) void hybrid_window_kernel(WindowArgs a) {
+  typedef Lane<E, VEC> Ln;
+  typedef typename E::T elem_t;
+  const elem_t* X = reinterpret_cast<const elem_t*>(a.X);
+  elem_t* Z = reinterpret_cast<elem_t*>(a.Z);
+  __shared__ int s_U[kChunkK];
+  __shared__ unsigned int s_mask[kChunkK / 4 * 2];  // 64-bit lane masks as two 32-bit halves
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nthreads = (int)blockDim.x, nwaves = nthreads >> 6;  // 1-4 waves: sized to the window's work
+  const int w = blockIdx.x;
+  const int r0 = w * 16, r1 = min(r0 + 16, a.N);
+  if (a.hybrid_type[w] == 0) {
+    constexpr int R = 64 / L;
+    const int G = R * nwaves;  // lane groups per workgroup
+    const int gi = wave * R + lane / L;
+    // rows up to kPlanFreeWide entries: one lane group each, strict CSR order
+    for (int rb = r0; rb < r1; rb += G) {  // uniform
+      const int r = rb + gi;
+      int e0 = 0, n = 0;
+      elem_t* dst = nullptr;
+      if (r < r1) {
+        e0 = a.rowptr[r];
+        n = a.rowptr[r + 1] - e0;
+        dst = Z + (size_t)r * a.ldz;
+        if (R > 1 && n > kPlanFreeWide) {  // left to the whole-wave pass below
+          n = 0;
+          dst = nullptr;
+        }
+      }
+      sparse_task<E, L, VEC, false>(X, dst, nullptr, a.col, e0, n, a.ldx, 0, a.D, lane);
+    }
+    // longer rows: whole waves (all 64/L lane groups on one row, shuffle-tree combine), dealt
+    // round-robin over the workgroup's waves -- a hub row no longer crawls on one lane group
+    if (R > 1) {
+      int k = 0;
+      for (int r = r0; r < r1; ++r) {  // uniform scan of the window's rows
+        const int e0 = a.rowptr[r];
+        const int n = a.rowptr[r + 1] - e0;
+        if (n > kPlanFreeWide) {
+          if (k % nwaves == wave)
+            sparse_task<E, L, VEC, true>(X, Z + (size_t)r * a.ldz, nullptr, a.col, e0, n, a.ldx, 0, a.D, lane);
+          ++k;
+        }
+      }
+    }
+    return;
+  }
+  const int lo = a.rowptr[r0], hi = a.rowptr[r1];
+  const int K = a.blockPartition[w] * 8;
+  const int n_panels = (a.D + 16 * VEC - 1) / (16 * VEC);
+  const int kq = lane >> 4, j = lane & 15;
+  for (int pb = 0; pb < n_panels; pb += nwaves) {  // uniform over the workgroup
+    const int panel = pb + wave;
+    const int c = panel * 16 * VEC + j * VEC;
+    const bool cok = panel < n_panels && c < a.D;
+    f32x4 acc[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += kChunkK) {  // uniform
+      const int kc = min(kChunkK, K - k0);
+      __syncthreads();
+      for (int i = threadIdx.x; i < kChunkK; i += nthreads) s_U[i] = -1;
+      for (int i = threadIdx.x; i < kChunkK / 2; i += nthreads) s_mask[i] = 0u;
+      __syncthreads();
+      for (int e = lo + (int)threadIdx.x; e < hi; e += nthreads) {
+        const int cc = a.edgeToColumn[e] - k0;
+        if (cc >= 0 && cc < kc) {
+          const int rl = a.edgeToRow[e] - r0;
+          const int bit = 16 * (cc & 3) + rl;  // MFMA A-operand lane of (row rl, k = cc & 3)
+          atomicOr(&s_mask[(cc >> 2) * 2 + (bit >> 5)], 1u << (bit & 31));
+          s_U[cc] = a.col[e];
+        }
+      }
+      __syncthreads();
+      const int steps = (kc + 3) / 4;
+      for (int t0 = 0; t0 < steps; t0 += 4) {
+        typename Ln::raw_t x[4];
+        float av[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int t = t0 + u;
+          const bool tv = t < steps;
+          const int idx = tv ? s_U[min(4 * t + kq, kChunkK - 1)] : -1;
+          const unsigned int mw = tv ? s_mask[t * 2 + (lane >> 5)] : 0u;
+          av[u] = ((mw >> (lane & 31)) & 1u) ? 1.0f : 0.0f;
+          x[u] = Ln::zero();
+          if (cok && idx >= 0) x[u] = Ln::load(X + (size_t)idx * a.ldx + c);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+          for (int q = 0; q < VEC; ++q)
+            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], Ln::elem(x[u], q), acc[q], 0, 0, 0);
+        }
+      }
+    }
+    if (cok) dense_store<E, VEC>(Z, acc, w, kq, c, a.N, a.ldz);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Host-side dispatch on (L, VEC).
+// ------------------------------------------------------------------------------------------
+template <typename E, int L, int VEC>
+static hipError_t launch_plan_LV(const PlanArgs& a, hipStream_t stream) {
+  constexpr int R = 64 / L;
+  PlanArgs b = a;
+  b.n_wide = (R > 1) ? a.n_wide : 0;  // with one lane group per wave a wide task is an ordinary one
+  b.wide_wgs = (b.n_wide + kWaves - 1) / kWaves;
+  b.tiny_wgs = (a.n_tiny + kWaves * R * TinyT<L>::value - 1) / (kWaves * R * TinyT<L>::value);
+  b.sparse_wgs_pp = b.wide_wgs + (a.n_tasks - a.n_tiny - b.n_wide + kWaves * R - 1) / (kWaves * R) + b.tiny_wgs;
+  const int n_col_panels = (a.D + a.panel_cols - 1) / a.panel_cols;
+  b.sparse_wgs = b.sparse_wgs_pp * n_col_panels;
+  if (b.sparse_wgs_pp == 0) b.sparse_wgs_pp = 1;  // divisor in the kernel
+  // dense-tile panel width: 16*dense_vec columns -- never wider than the embedding (idle MFMA lanes)
+  constexpr int VM = DenseV<VEC>::mid;
+  // (16-bit features have no 4-byte-per-lane build: 32 <= D < 64 takes the 8-byte one with half the lanes idle)
+  constexpr int kMidCols = (sizeof(typename E::T) == 2 && VM > 1) ? 8 * VM : 16 * VM;
+  b.dense_vec = (a.D >= 16 * VEC) ? VEC : (a.D >= kMidCols ? VM : 1);
+  b.n_panels = (a.D + 16 * b.dense_vec - 1) / (16 * b.dense_vec);
+  const long long dense_units = (long long)a.n_dense * b.n_panels;
+  const long long dense_wgs = (dense_units + kWaves - 1) / kWaves;
+  const long long grid = (long long)b.sparse_wgs + dense_wgs;
+  if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  if (grid > 0) {
+    hipLaunchKernelGGL((hybrid_plan_kernel<E, L, VEC, HCSPMM_SPARSE_U, HCSPMM_MIN_WAVES_PER_SIMD>), dim3((unsigned)grid),
+                       dim3(kThreads), 0, stream, b);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if (a.n_split_rows > 0) {
+    const int fg = (a.n_split_rows + kWaves - 1) / kWaves;
+    hipLaunchKernelGGL((fixup_kernel<E, VEC>), dim3(fg), dim3(kThreads), 0, stream, b);
+    e = hipGetLastError();
+  }
+  return e;
+}
+
+template <typename E, int L, int VEC>
+static hipError_t launch_window_LV(const WindowArgs& a, hipStream_t stream) {
+  const int W = (a.N + 15) / 16;
+  // 16 rows x L lanes of sparse work, D/(16*VEC) dense panels: narrow embeddings get narrower workgroups
+  // (a 256-thread workgroup per window is dispatch-bound when each window holds a handful of entries)
+  const int n_panels = (a.D + 16 * VEC - 1) / (16 * VEC);
+  int waves = (16 * L + 63) / 64;
+  if (n_panels > waves) waves = n_panels;
+  if (waves > kWaves) waves = kWaves;
+  if (W > 0) hipLaunchKernelGGL((hybrid_window_kernel<E, L, VEC>), dim3(W), dim3(waves * 64), 0, stream, a);
+  return hipGetLastError();
+}
+
+// lanes per task: smallest power of two >= D / VEC, clamped to [4, 64]
+static inline int pick_L(int D, int VEC) {
+  const int slots = (D + VEC - 1) / VEC;
+  int L = 4;
+  while (L < slots && L < 64) L <<= 1;
+  return L;
+}
+
+#define HCSPMM_DISPATCH_L(FN, E, VEC, WIDTH, ARGS, STREAM)  \
+  switch (pick_L((WIDTH), VEC)) {                           \
+    case 4:  return FN<E, 4, VEC>(ARGS, STREAM);            \
+    case 8:  return FN<E, 8, VEC>(ARGS, STREAM);            \
+    case 16: return FN<E, 16, VEC>(ARGS, STREAM);           \
+    case 32: return FN<E, 32, VEC>(ARGS, STREAM);           \
+    default: return FN<E, 64, VEC>(ARGS, STREAM);           \
+  }
+
+}  // namespace hcspmm

@@ -8,8 +8,8 @@ namespace hcspmm {
 // Arguments of the planned hybrid launch (device pointers; `plan` is the uploaded blob of
 // hcspmm_plan_build, the off_* / n_* fields are copied from the host copy of its header).
 struct PlanArgs {
-  const float* X;
-  float* Z;
+  const void* X;  // features, element type of the launch (fp32, or fp16 / bf16 bits)
+  void* Z;
   float* partial;  // workspace: n_partials x D partial sums of split rows
   const int* col;
   const int* plan;
@@ -29,8 +29,8 @@ struct PlanArgs {
 
 // Arguments of the plan-free launch: the reference's seven graph tensors as they are.
 struct WindowArgs {
-  const float* X;
-  float* Z;
+  const void* X;
+  void* Z;
   const int* rowptr;
   const int* col;
   const int* blockPartition;
@@ -41,10 +41,14 @@ struct WindowArgs {
   int N, D;
 };
 
-// vec = floats per lane access (4, 2 or 1): the caller guarantees D, ldx, ldz % vec == 0 and that X, Z
-// and the workspace are aligned to 4*vec bytes.
-hipError_t launch_plan(const PlanArgs& a, int vec, hipStream_t stream);
-hipError_t launch_window(const WindowArgs& a, int vec, hipStream_t stream);
+// vec = elements per lane access (fp32: 4, 2 or 1; 16-bit: 8, 4 or 1): the caller guarantees D, ldx,
+// ldz % vec == 0, that X and Z are aligned to vec elements and the fp32 workspace to 4*vec bytes.
+hipError_t launch_plan_f32(const PlanArgs& a, int vec, hipStream_t stream);
+hipError_t launch_window_f32(const WindowArgs& a, int vec, hipStream_t stream);
+hipError_t launch_plan_f16(const PlanArgs& a, int vec, hipStream_t stream);
+hipError_t launch_window_f16(const WindowArgs& a, int vec, hipStream_t stream);
+hipError_t launch_plan_bf16(const PlanArgs& a, int vec, hipStream_t stream);
+hipError_t launch_window_bf16(const WindowArgs& a, int vec, hipStream_t stream);
 
 // out[N x H] = in[N x D] * W (D x H, element strides ldr / ldc), fp32 MFMA.
 hipError_t launch_dense_update(const float* in, const float* W, long long ldr, long long ldc, float* out, int N,

@@ -1,700 +1,19 @@
-// spmm_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the hybrid SpMM  Z = A * X.
-//
-// Replaces the reference kernels spmm_forward_cuda_kernel_arbi_warps_hybrid_{adaptive,32,64,
-// adaptive_more} (hybrid_kernel/hybrid_all_kernel.cu:919-1637).  Nothing here is derived from
-// their structure: the reference runs one 96-thread block per 16-row window with warp-per-row
-// gathers and WMMA tf32 tiles staged through shared memory; this file is wave64 code built
-// around two facts of the machine (see /DESIGN.md):
-//
-//  * sparse-row path: the launch is bound by the gathered X-row bytes that miss the per-XCD L2, so
-//    (a) rows become *tasks* ordered by power-of-two length class (host plan); L lanes of a wave own
-//    one task and walk its neighbours strictly in CSR order (bit-identical to a sequential fp32
-//    sum), 64/L tasks share a wave; the longest tasks go to whole waves ("wide", shuffle-tree
-//    combine); (b) wide embeddings are processed panel-major, 32 columns (one cache line per row)
-//    at a time across the whole grid; (c) column indices are fetched coalesced once per L
-//    neighbours and broadcast through the LDS crossbar (ds_bpermute); every lane issues 16-byte
-//    loads in branch-free batches of 8.
-//  * dense-tile path: v_mfma_f32_16x16x4_f32 takes its B operand one fp32 per lane, so the
-//    gathered X rows go from HBM straight into MFMA operand registers with 16-byte loads (the
-//    four floats of a lane feed four MFMAs whose results re-assemble into a 16-byte store);
-//    the 0/1 tile of A arrives as a 64-bit lane mask per k-step, packed by the host in MFMA
-//    lane order.  No LDS round trip, no barrier.  fp32 MFMA is an exact k-ordered fma chain,
-//    so the result equals the sequential sum over the window's ascending unique columns.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-
-#include "hcspmm.h"
-#include "spmm_kernels.h"
+// spmm_kernels.hip -- fp32 instantiations of the hybrid SpMM kernels (spmm_impl.h holds the device code).
+#include "spmm_impl.h"
 
 namespace hcspmm {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-template <int VEC> struct VecT;
-template <> struct VecT<4> { typedef f32x4 type; };
-template <> struct VecT<2> { typedef f32x2 type; };
-template <> struct VecT<1> { typedef float type; };
-
-template <int VEC> __device__ __forceinline__ typename VecT<VEC>::type vzero();
-template <> __device__ __forceinline__ f32x4 vzero<4>() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
-template <> __device__ __forceinline__ f32x2 vzero<2>() { return f32x2{0.f, 0.f}; }
-template <> __device__ __forceinline__ float vzero<1>() { return 0.f; }
-
-__device__ __forceinline__ float vget(const f32x4& v, int i) { return v[i]; }
-__device__ __forceinline__ float vget(const f32x2& v, int i) { return v[i]; }
-__device__ __forceinline__ float vget(const float& v, int) { return v; }
-__device__ __forceinline__ void vset(f32x4& v, int i, float x) { v[i] = x; }
-__device__ __forceinline__ void vset(f32x2& v, int i, float x) { v[i] = x; }
-__device__ __forceinline__ void vset(float& v, int, float x) { v = x; }
-
-#ifndef HCSPMM_LDS_STAGE
-#define HCSPMM_LDS_STAGE 0  // 1: A/B build that stages the gathered rows through LDS (see sparse_task)
-#endif
-#ifndef HCSPMM_NT_STORE
-#define HCSPMM_NT_STORE 1  // Z rows are written once and not re-read by this launch: non-temporal stores (0-5 %, profiles/r01/ab_nt_store.log)
-#endif
-template <typename V>
-__device__ __forceinline__ void store_out(V* p, const V& v) {
-#if HCSPMM_NT_STORE
-  __builtin_nontemporal_store(v, p);
-#else
-  *p = v;
-#endif
-}
-constexpr int kWaves = 4;            // waves per workgroup (256 threads)
-constexpr int kThreads = kWaves * 64;
-#ifndef HCSPMM_SPARSE_U
-#define HCSPMM_SPARSE_U 8  // row loads in flight per lane on the sparse-row path
-#endif
-#ifndef HCSPMM_DENSE_B
-#define HCSPMM_DENSE_B 8   // k-steps (row loads in flight per lane) per batch on the dense-tile path
-#endif
-#ifndef HCSPMM_TINY_PER_WAVE
-#define HCSPMM_TINY_PER_WAVE 8  // tiny tasks (<= 2 entries) per wave: T = 8 / (64/L) per lane group, at least 2, at most 4
-#endif                          // (D = 32: T = 2 vs 4 vs 8 in profiles/r01/ab_tiny_tasks.log; wide D: ab_tiny_tasks_wide.log;
-                                //  T = 8 costs the L = 32 build its fifth wave per SIMD: 119 instead of 94 registers)
-template <int L> struct TinyT {
-  static constexpr int per_group = HCSPMM_TINY_PER_WAVE / (64 / L);
-  static constexpr int value = per_group < 2 ? 2 : (per_group > 4 ? 4 : per_group);
-};
-#ifndef HCSPMM_MIN_WAVES_PER_SIMD
-#define HCSPMM_MIN_WAVES_PER_SIMD 4  // <= 128 registers per lane (measured best with U = B = 8: profiles/r01/ab_u_b_mw_v2.log)
-#endif
-
-// One branch-free batch of UB row gathers: every lane issues all UB loads (finished tasks and lanes
-// beyond the embedding width re-read row 0 / column 0, an L1 hit, and discard it), so the batch is one
-// basic block -- UB broadcasts, UB address computations, UB loads back to back, counted waits.
-template <int VEC, int UB>
-__device__ __forceinline__ void gather_batch(const float* __restrict__ X, size_t ldx, int csafe, bool cok, int myidx,
-                                             int src0, typename VecT<VEC>::type& acc, int lane, float* lds_stage,
-                                             const int* prefetch_from, int& prefetched) {
-  typedef typename VecT<VEC>::type vec_t;
-  int idx[UB];
-  vec_t v[UB];
-#pragma unroll
-  for (int u = 0; u < UB; ++u) idx[u] = __shfl(myidx, src0 + u, 64);
-  // the next chunk's indices are requested here -- after this chunk's were broadcast, ahead of its row
-  // loads -- so they arrive under those loads and a chunk costs one round trip, not two
-  if (prefetch_from != nullptr) prefetched = *prefetch_from;
-#if HCSPMM_LDS_STAGE
-  // Experiment (north_star's "staged through LDS"): the batch's rows go HBM -> LDS by LDS-DMA
-  // (global_load_lds_dwordx4: per-lane source address, wave-linear destination), then each lane reads
-  // its 16 bytes back.  Same bytes, one extra LDS round trip; measured in profiles/r01/ab_lds_stage.log.
-  if (VEC == 4 && lds_stage != nullptr) {  // (the plan-free kernel passes no staging area)
-    float* stage = lds_stage + (threadIdx.x >> 6) * (HCSPMM_SPARSE_U * 256);  // 1 KiB per load per wave
-#pragma unroll
-    for (int u = 0; u < UB; ++u)
-      __builtin_amdgcn_global_load_lds(X + (size_t)max(idx[u], 0) * ldx + csafe, stage + u * 256, 16, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int u = 0; u < UB; ++u) v[u] = *reinterpret_cast<const vec_t*>(stage + u * 256 + lane * 4);
-  } else
-#endif
-  {
-#pragma unroll
-    for (int u = 0; u < UB; ++u) v[u] = *reinterpret_cast<const vec_t*>(X + (size_t)max(idx[u], 0) * ldx + csafe);
-  }
-#pragma unroll
-  for (int u = 0; u < UB; ++u) {
-    if (!(cok && idx[u] >= 0)) v[u] = vzero<VEC>();
-    acc += v[u];
-  }
+// vec = elements per lane access (4, 2 or 1): the caller guarantees D, ldx, ldz % vec == 0 and the alignment.
+hipError_t launch_plan_f32(const PlanArgs& a, int vec, hipStream_t stream) {
+  if (vec == 4) { HCSPMM_DISPATCH_L(launch_plan_LV, F32, 4, a.panel_cols, a, stream) }
+  if (vec == 2) { HCSPMM_DISPATCH_L(launch_plan_LV, F32, 2, a.panel_cols, a, stream) }
+  HCSPMM_DISPATCH_L(launch_plan_LV, F32, 1, a.panel_cols, a, stream)
 }
 
-// ------------------------------------------------------------------------------------------
-// Sparse-row task body: the L lanes [lane & ~(L-1), +L) own one task (row or row segment)
-// = CSR entries [e0, e0 + n); lane slot s covers columns pbase + s*VEC .. +VEC.  All control
-// flow is wave-uniform (loop bounds come from the wave-wide maximum n); shorter tasks are
-// predicated off by idx = -1, and adding the resulting 0.0f is exact.
-// ------------------------------------------------------------------------------------------
-template <int L, int VEC, bool WIDE, int UMAX = HCSPMM_SPARSE_U>
-__device__ __forceinline__ void sparse_task(const float* __restrict__ X, float* __restrict__ dst,
-                                            const int* __restrict__ col, int e0, int n, size_t ldx, int c0,
-                                            int cend, int lane, float* lds_stage = nullptr) {
-  typedef typename VecT<VEC>::type vec_t;
-  constexpr int U = (L < UMAX) ? L : UMAX;  // loads in flight per lane
-  // WIDE: the whole wave owns ONE task (e0, n wave-uniform); per 64-entry super-chunk lane i holds
-  // entry base+i, so lane group g sums entries [base + g*L, base + (g+1)*L) and the 64/L group sums
-  // are combined by a fixed xor-shuffle tree at the end.  Otherwise each lane group owns its own task.
-  constexpr int STRIDE = WIDE ? 64 : L;
-  const int s = lane & (L - 1);
-  const int pos = WIDE ? lane : s;
-  const int gbase = lane & ~(L - 1);
-  int nmax = n;
-  if (!WIDE) {
-#pragma unroll
-    for (int off = L; off < 64; off <<= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
-  }
-  nmax = __builtin_amdgcn_readfirstlane(nmax);
-
-  for (int pbase = c0; pbase < cend; pbase += L * VEC) {  // feature columns [c0, cend) of the rows
-    const int c = pbase + s * VEC;
-    const bool cok = c < cend;
-    const int csafe = cok ? c : 0;
-    vec_t acc = vzero<VEC>();
-    int next = (pos < n) ? col[e0 + pos] : -1;
-    for (int base = 0; base < nmax; base += STRIDE) {
-      const int myidx = next;
-      const bool more = base + STRIDE + pos < n;
-      next = -1;
-      const int cnt = min(L, nmax - base);  // longest lane group's share of this chunk
-      const int* pf = more ? col + e0 + base + STRIDE + pos : nullptr;  // consumed by the chunk's first batch
-      for (int j = 0; j < cnt;) {
-        const int left = cnt - j;  // wave-uniform: short tasks (the bulk of a low-degree graph) get
-        if (left > U / 2) {        // short batches instead of a full one padded with dummy loads
-          gather_batch<VEC, U>(X, ldx, csafe, cok, myidx, gbase + j, acc, lane, lds_stage, pf, next);
-          j += U;
-        } else if (U >= 8 && left > U / 4) {
-          gather_batch<VEC, (U >= 8 ? U / 2 : 1)>(X, ldx, csafe, cok, myidx, gbase + j, acc, lane, lds_stage, pf, next);
-          j += U / 2;
-        } else if (U >= 4 && left > 1) {
-          gather_batch<VEC, (U >= 8 ? U / 4 : 2)>(X, ldx, csafe, cok, myidx, gbase + j, acc, lane, lds_stage, pf, next);
-          j += (U >= 8 ? U / 4 : 2);
-        } else {
-          gather_batch<VEC, 1>(X, ldx, csafe, cok, myidx, gbase + j, acc, lane, lds_stage, pf, next);
-          j += 1;
-        }
-        pf = nullptr;
-      }
-    }
-    if (WIDE) {
-#pragma unroll
-      for (int off = L; off < 64; off <<= 1) {
-#pragma unroll
-        for (int q = 0; q < VEC; ++q) vset(acc, q, vget(acc, q) + __shfl_xor(vget(acc, q), off, 64));
-      }
-      if (cok && dst != nullptr && lane < L) store_out(reinterpret_cast<vec_t*>(dst + c), acc);
-    } else {
-      if (cok && dst != nullptr) store_out(reinterpret_cast<vec_t*>(dst + c), acc);
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// Tiny tasks (at most two entries, indices inline in the descriptor: hcspmm.h n_tiny).  On a low-degree
-// graph these are most of the rows, and a wave that handles 64/L of them is a chain of dependent round
-// trips (descriptor -> indices -> rows -> store) with one or two loads in flight per lane: latency, not
-// bandwidth, sets the time (tools/lowdeg_breakdown.py).  Here each lane group takes T tasks at once: T
-// independent descriptor loads, then up to 2T independent row loads, then T stores -- two round trips
-// per T tasks.  The sum is 0 + x[index0] + x[index1] in that order: the sequential CSR order.
-// ------------------------------------------------------------------------------------------
-template <int L, int VEC, int T>
-__device__ __forceinline__ void tiny_tasks(const PlanArgs& a, int first, int c0, int cend, int lane) {
-  typedef typename VecT<VEC>::type vec_t;
-  constexpr int R = 64 / L;
-  const int g = lane / L, s = lane & (L - 1);
-  const int4* tasks = reinterpret_cast<const int4*>(a.plan + a.off_tasks);
-  int4 d[T];
-  bool any1 = false, any2 = false;
-#pragma unroll
-  for (int t = 0; t < T; ++t) {
-    const int tid = first + t * R + g;  // consecutive tasks (= ascending rows) across the lane groups
-    d[t] = (tid < a.n_tasks) ? tasks[tid] : int4{0, -1, -1, -1};  // .z < 0: no task
-  }
-#pragma unroll
-  for (int t = 0; t < T; ++t) {
-    any1 |= d[t].y >= 0;
-    any2 |= d[t].w >= 0;
-  }
-  any1 = __builtin_amdgcn_ballot_w64(any1) != 0;  // wave-uniform: a wave inside the 0- or 1-entry class issues
-  any2 = __builtin_amdgcn_ballot_w64(any2) != 0;  // no loads for the absent entries
-  for (int pbase = c0; pbase < cend; pbase += L * VEC) {
-    const int c = pbase + s * VEC;
-    const bool cok = c < cend;
-    const int csafe = cok ? c : 0;
-    vec_t v0[T], v1[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) v0[t] = v1[t] = vzero<VEC>();
-    if (any1) {
-#pragma unroll
-      for (int t = 0; t < T; ++t) v0[t] = *reinterpret_cast<const vec_t*>(a.X + (size_t)max(d[t].y, 0) * a.ldx + csafe);
-    }
-    if (any2) {
-#pragma unroll
-      for (int t = 0; t < T; ++t) v1[t] = *reinterpret_cast<const vec_t*>(a.X + (size_t)max(d[t].w, 0) * a.ldx + csafe);
-    }
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-      vec_t acc = vzero<VEC>();
-      if (d[t].y >= 0) acc += v0[t];
-      if (d[t].w >= 0) acc += v1[t];
-      if (cok && d[t].z >= 0) {
-        float* dst = (d[t].x >= 0) ? a.Z + (size_t)d[t].x * a.ldz : a.partial + (size_t)(-(d[t].x + 1)) * (size_t)a.D;
-        store_out(reinterpret_cast<vec_t*>(dst + c), acc);
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// Dense-tile unit: one wave = (dense window, panel of 16*VEC feature columns).
-// MFMA operand maps (v_mfma_f32_16x16x4_f32): lane l supplies A[i = l & 15][k = l >> 4] and
-// B[k = l >> 4][j = l & 15]; accumulator register r of lane l is D[4*(l >> 4) + r][l & 15].
-// Instruction q of a k-step multiplies by feature column  panel + j*VEC + q, so after the VEC
-// instructions lane l holds Z[row 4*(l>>4)+r][panel + j*VEC .. +VEC) -- a contiguous vector.
-// ------------------------------------------------------------------------------------------
-template <int VEC>
-__device__ __forceinline__ void dense_unit(const float* __restrict__ X, float* __restrict__ Z,
-                                           const int* __restrict__ U, const unsigned long long* __restrict__ masks,
-                                           int K4, int window, int panel, int N, int D, size_t ldx, size_t ldz,
-                                           int lane) {
-  typedef typename VecT<VEC>::type vec_t;
-  const int kq = lane >> 4, j = lane & 15;
-  const int c = panel * 16 * VEC + j * VEC;
-  const bool cok = c < D;
-  const int csafe = cok ? c : 0;
-  f32x4 acc[VEC];
-#pragma unroll
-  for (int q = 0; q < VEC; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  for (int kb = 0; kb < K4; kb += 16) {
-    const int myU = (kb * 4 + lane < K4 * 4) ? U[kb * 4 + lane] : -1;
-    const int steps = min(16, K4 - kb);
-    constexpr int B = HCSPMM_DENSE_B * (4 / VEC);  // same bytes in flight per lane whatever the panel width
-    for (int t0 = 0; t0 < steps; t0 += B) {
-      // Branch-free batch (see sparse_task): padded columns (U = -1) and steps past the end re-read
-      // row 0 and are zeroed by the select; their A tile is zero as well.
-      int idx[B];
-      vec_t x[B];
-      float a[B];
-#pragma unroll
-      for (int u = 0; u < B; ++u) {
-        const int t = t0 + u;
-        idx[u] = __shfl(myU, (4 * t + kq) & 63, 64);
-        const unsigned long long m = masks[min(kb + t, K4 - 1)];  // wave-uniform address: scalar load
-        a[u] = (t < steps && ((m >> lane) & 1ull)) ? 1.0f : 0.0f;
-        if (t >= steps) idx[u] = -1;
-      }
-#pragma unroll
-      for (int u = 0; u < B; ++u) x[u] = *reinterpret_cast<const vec_t*>(X + (size_t)max(idx[u], 0) * ldx + csafe);
-#pragma unroll
-      for (int u = 0; u < B; ++u) {
-        if (!(cok && idx[u] >= 0)) x[u] = vzero<VEC>();
-        if (t0 + u < steps) {  // wave-uniform: no MFMA issue slots for the padding of a short batch
-#pragma unroll
-          for (int q = 0; q < VEC; ++q)
-            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], vget(x[u], q), acc[q], 0, 0, 0);
-        }
-      }
-    }
-  }
-  if (cok) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = window * 16 + 4 * kq + r;
-      if (row < N) {
-        vec_t o;
-#pragma unroll
-        for (int q = 0; q < VEC; ++q) vset(o, q, acc[q][r]);
-        store_out(reinterpret_cast<vec_t*>(Z + (size_t)row * ldz + c), o);
-      }
-    }
-  }
-}
-
-// Compact dense unit: a window of at most 32 (padded) columns whose whole description is one 64-word
-// record at an address that follows from the unit number (hcspmm.h n_dense_compact): lane l loads word l
-// -- one coalesced 256-byte load -- and the wave can gather: window / K4 / masks go to scalar registers
-// (v_readlane), the column list is broadcast as in dense_unit.  Two round trips per unit instead of three.
-// Same MFMA chain as dense_unit, so the same bits.
-template <int VEC, int STEPS>
-__device__ __forceinline__ void compact_steps(const float* __restrict__ X, int word, int K4, int csafe, bool cok,
-                                              size_t ldx, int lane, f32x4 (&acc)[VEC], int t_base) {
-  typedef typename VecT<VEC>::type vec_t;
-  const int kq = lane >> 4;
-  int idx[STEPS];
-  vec_t x[STEPS];
-  float a[STEPS];
-#pragma unroll
-  for (int u = 0; u < STEPS; ++u) {
-    const int t = t_base + u;
-    idx[u] = __shfl(word, 2 + 4 * t + kq, 64);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane(word, 2 + HCSPMM_COMPACT_K + 2 * t);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane(word, 3 + HCSPMM_COMPACT_K + 2 * t);
-    const unsigned long long m = ((unsigned long long)hi << 32) | lo;
-    a[u] = (t < K4 && ((m >> lane) & 1ull)) ? 1.0f : 0.0f;
-    if (t >= K4) idx[u] = -1;
-  }
-#pragma unroll
-  for (int u = 0; u < STEPS; ++u) x[u] = *reinterpret_cast<const vec_t*>(X + (size_t)max(idx[u], 0) * ldx + csafe);
-#pragma unroll
-  for (int u = 0; u < STEPS; ++u) {
-    if (!(cok && idx[u] >= 0)) x[u] = vzero<VEC>();
-    if (t_base + u < K4) {  // wave-uniform
-#pragma unroll
-      for (int q = 0; q < VEC; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], vget(x[u], q), acc[q], 0, 0, 0);
-    }
-  }
-}
-
-template <int VEC>
-__device__ __forceinline__ void dense_compact_unit(const float* __restrict__ X, float* __restrict__ Z,
-                                                   const int* __restrict__ rec, int panel, int N, int D, size_t ldx,
-                                                   size_t ldz, int lane) {
-  typedef typename VecT<VEC>::type vec_t;
-  const int word = rec[lane];
-  const int window = __builtin_amdgcn_readlane(word, 0);
-  const int K4 = __builtin_amdgcn_readlane(word, 1);
-  const int kq = lane >> 4, j = lane & 15;
-  const int c = panel * 16 * VEC + j * VEC;
-  const bool cok = c < D;
-  const int csafe = cok ? c : 0;
-  f32x4 acc[VEC];
-#pragma unroll
-  for (int q = 0; q < VEC; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (K4 <= 2) {
-    compact_steps<VEC, 2>(X, word, K4, csafe, cok, ldx, lane, acc, 0);
-  } else if (K4 <= 4) {
-    compact_steps<VEC, 4>(X, word, K4, csafe, cok, ldx, lane, acc, 0);
-  } else {
-    compact_steps<VEC, 8>(X, word, K4, csafe, cok, ldx, lane, acc, 0);
-  }
-  if (cok) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = window * 16 + 4 * kq + r;
-      if (row < N) {
-        vec_t o;
-#pragma unroll
-        for (int q = 0; q < VEC; ++q) vset(o, q, acc[q][r]);
-        store_out(reinterpret_cast<vec_t*>(Z + (size_t)row * ldz + c), o);
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// Planned hybrid kernel: ONE launch covers both sub-paths (as the reference's single launch
-// does, K.cu:960/1039) -- per column panel, workgroups [0, wide_wgs) run wide sparse tasks, then ordinary
-// ones, then tiny ones (the last tiny_wgs); after all sparse panels come the dense units.
-// ------------------------------------------------------------------------------------------
-// UNROLL row loads in flight per lane, MINW waves per SIMD the register budget must allow.  With the
-// branch-free batches <8, 4> is best for throughput- and latency-bound launches alike
-// (profiles/r01/ab_u_b_mw_v2.log; before them <4, 8> won: profiles/r01/ab_u_b_mw.log).
-__device__ __forceinline__ int sparse_wgs_pp_ordinary_end(const PlanArgs& a) { return a.sparse_wgs_pp - a.tiny_wgs; }
-
-template <int L, int VEC, int UNROLL, int MINW>
-__global__ __launch_bounds__(kThreads, MINW) void hybrid_plan_kernel(PlanArgs a) {
-#if HCSPMM_LDS_STAGE
-  __shared__ __attribute__((aligned(16))) float s_stage[kWaves * UNROLL * 256];
-  float* lds_stage = s_stage;
-#else
-  float* lds_stage = nullptr;
-#endif
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if ((int)blockIdx.x < a.sparse_wgs) {
-    // column-panel-major: every sparse task runs once per panel of a.panel_cols feature columns, and
-    // all workgroups of panel p precede those of panel p+1, so at any time the gathers touch one
-    // 128-byte slice of the X rows -- four times as many distinct rows fit the per-XCD L2
-    const int p = (int)blockIdx.x / a.sparse_wgs_pp;
-    const int b = (int)blockIdx.x - p * a.sparse_wgs_pp;
-    const int c0 = p * a.panel_cols;
-    const int cend = min(a.D, c0 + a.panel_cols);
-    if (b < a.wide_wgs) {
-      // wide tasks: the a.n_wide longest tasks, one per wave
-      const int tid = b * kWaves + wave;
-      if (tid >= a.n_wide) return;
-      const int4 t = reinterpret_cast<const int4*>(a.plan + a.off_tasks)[tid];
-      float* dst = (t.w < 0) ? a.Z + (size_t)t.x * a.ldz : a.partial + (size_t)t.w * (size_t)a.D;
-      sparse_task<L, VEC, true, UNROLL>(a.X, dst, a.col, __builtin_amdgcn_readfirstlane(t.y),
-                                        __builtin_amdgcn_readfirstlane(t.z), a.ldx, c0, cend, lane, lds_stage);
-    } else if (b >= sparse_wgs_pp_ordinary_end(a)) {
-      constexpr int R = 64 / L;
-      const int first = a.n_tasks - a.n_tiny + ((b - sparse_wgs_pp_ordinary_end(a)) * kWaves + wave) * (R * TinyT<L>::value);
-      if (first >= a.n_tasks) return;
-      tiny_tasks<L, VEC, TinyT<L>::value>(a, first, c0, cend, lane);
-    } else {
-      constexpr int R = 64 / L;
-      const int g = lane / L;
-      const int tid = a.n_wide + ((b - a.wide_wgs) * kWaves + wave) * R + g;
-      int e0 = 0, n = 0;
-      float* dst = nullptr;
-      if (tid < a.n_tasks - a.n_tiny) {
-        const int4 t = reinterpret_cast<const int4*>(a.plan + a.off_tasks)[tid];
-        e0 = t.y;
-        n = t.z;
-        dst = (t.w < 0) ? a.Z + (size_t)t.x * a.ldz : a.partial + (size_t)t.w * (size_t)a.D;
-      }
-      sparse_task<L, VEC, false, UNROLL>(a.X, dst, a.col, e0, n, a.ldx, c0, cend, lane, lds_stage);
-    }
-  } else {
-    int unit = ((int)blockIdx.x - a.sparse_wgs) * kWaves + wave;
-    if (unit >= a.n_dense * a.n_panels) return;
-    const int n_reg = a.n_dense - a.n_dense_compact;  // regular windows (K > 32) first, widest first
-    if (unit >= n_reg * a.n_panels) {
-      unit -= n_reg * a.n_panels;
-      const int panel = unit / a.n_dense_compact, ci = unit - panel * a.n_dense_compact;  // panel-major
-      const int* rec = a.plan + a.off_dense_compact + ci * HCSPMM_COMPACT_WORDS;
-      if (VEC >= 4 && a.dense_vec == 4) dense_compact_unit<(VEC >= 4 ? 4 : 1)>(a.X, a.Z, rec, panel, a.N, a.D, a.ldx, a.ldz, lane);
-      else if (VEC >= 2 && a.dense_vec == 2) dense_compact_unit<(VEC >= 2 ? 2 : 1)>(a.X, a.Z, rec, panel, a.N, a.D, a.ldx, a.ldz, lane);
-      else dense_compact_unit<1>(a.X, a.Z, rec, panel, a.N, a.D, a.ldx, a.ldz, lane);
-      return;
-    }
-    const int panel = unit / n_reg, di = unit - panel * n_reg;  // panel-major, like the sparse region
-    const int4 d = reinterpret_cast<const int4*>(a.plan + a.off_dense_index)[di];
-    const int* U = a.plan + a.off_dense_pack + d.y;
-    const unsigned long long* masks = reinterpret_cast<const unsigned long long*>(U + 4 * d.z);
-    // floats per lane on the dense-tile path (a panel is 16*dvec columns): set by the launcher from D
-    if (VEC >= 4 && a.dense_vec == 4) dense_unit<(VEC >= 4 ? 4 : 1)>(a.X, a.Z, U, masks, d.z, d.x, panel, a.N, a.D, a.ldx, a.ldz, lane);
-    else if (VEC >= 2 && a.dense_vec == 2) dense_unit<(VEC >= 2 ? 2 : 1)>(a.X, a.Z, U, masks, d.z, d.x, panel, a.N, a.D, a.ldx, a.ldz, lane);
-    else dense_unit<1>(a.X, a.Z, U, masks, d.z, d.x, panel, a.N, a.D, a.ldx, a.ldz, lane);
-  }
-}
-
-// Fix-up: rows that were split into segments -- Z[row] = partial[s0] + partial[s0+1] + ... in
-// segment order (deterministic).  One wave per split row.
-template <int VEC>
-__global__ __launch_bounds__(kThreads) void fixup_kernel(PlanArgs a) {
-  typedef typename VecT<VEC>::type vec_t;
-  const int lane = threadIdx.x & 63;
-  const int fi = (int)blockIdx.x * kWaves + (threadIdx.x >> 6);
-  if (fi >= a.n_split_rows) return;
-  const int4 f = reinterpret_cast<const int4*>(a.plan + a.off_fixups)[fi];
-  const int row = f.x, s0 = f.y, ns = f.z;
-  for (int c = lane * VEC; c < a.D; c += 64 * VEC) {
-    const float* p = a.partial + (size_t)s0 * (size_t)a.D + c;
-    vec_t acc = *reinterpret_cast<const vec_t*>(p);
-    int s = 1;
-    for (; s + 4 <= ns; s += 4) {  // four independent loads in flight, added in segment order
-      vec_t v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const vec_t*>(p + (size_t)(s + u) * (size_t)a.D);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) acc += v[u];
-    }
-    for (; s < ns; ++s) acc += *reinterpret_cast<const vec_t*>(p + (size_t)s * (size_t)a.D);
-    store_out(reinterpret_cast<vec_t*>(a.Z + (size_t)row * a.ldz + c), acc);
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// Plan-free kernel (callers that pass the reference's [0] placeholders): one workgroup per
-// 16-row window, branch on hybrid_type[window] exactly like the reference launch.  Sparse
-// windows deal their rows to the workgroup's lane groups; dense windows rebuild the window's
-// unique-column list and tile masks in LDS from edgeToColumn / edgeToRow / column_index (the
-// reference builds sparse_A / sparse_AToX_index the same way, K.cu:1067-1074) in chunks of
-// kChunkK condensed columns, so any blockPartition is handled.
-// ------------------------------------------------------------------------------------------
-constexpr int kChunkK = 512;  // condensed columns per LDS pass (128 k-steps)
-constexpr int kPlanFreeWide = 64;  // plan-free kernel: rows longer than this are summed by a whole wave
-
-template <int L, int VEC>
-__global__ __launch_bounds__(kThreads) void hybrid_window_kernel(WindowArgs a) {
-  __shared__ int s_U[kChunkK];
-  __shared__ unsigned int s_mask[kChunkK / 4 * 2];  // 64-bit lane masks as two 32-bit halves
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nthreads = (int)blockDim.x, nwaves = nthreads >> 6;  // 1-4 waves: sized to the window's work
-  const int w = blockIdx.x;
-  const int r0 = w * 16, r1 = min(r0 + 16, a.N);
-  if (a.hybrid_type[w] == 0) {
-    constexpr int R = 64 / L;
-    const int G = R * nwaves;  // lane groups per workgroup
-    const int gi = wave * R + lane / L;
-    // rows up to kPlanFreeWide entries: one lane group each, strict CSR order
-    for (int rb = r0; rb < r1; rb += G) {  // uniform
-      const int r = rb + gi;
-      int e0 = 0, n = 0;
-      float* dst = nullptr;
-      if (r < r1) {
-        e0 = a.rowptr[r];
-        n = a.rowptr[r + 1] - e0;
-        dst = a.Z + (size_t)r * a.ldz;
-        if (R > 1 && n > kPlanFreeWide) {  // left to the whole-wave pass below
-          n = 0;
-          dst = nullptr;
-        }
-      }
-      sparse_task<L, VEC, false>(a.X, dst, a.col, e0, n, a.ldx, 0, a.D, lane);
-    }
-    // longer rows: whole waves (all 64/L lane groups on one row, shuffle-tree combine), dealt
-    // round-robin over the workgroup's waves -- a hub row no longer crawls on one lane group
-    if (R > 1) {
-      int k = 0;
-      for (int r = r0; r < r1; ++r) {  // uniform scan of the window's rows
-        const int e0 = a.rowptr[r];
-        const int n = a.rowptr[r + 1] - e0;
-        if (n > kPlanFreeWide) {
-          if (k % nwaves == wave)
-            sparse_task<L, VEC, true>(a.X, a.Z + (size_t)r * a.ldz, a.col, e0, n, a.ldx, 0, a.D, lane);
-          ++k;
-        }
-      }
-    }
-    return;
-  }
-  typedef typename VecT<VEC>::type vec_t;
-  const int lo = a.rowptr[r0], hi = a.rowptr[r1];
-  const int K = a.blockPartition[w] * 8;
-  const int n_panels = (a.D + 16 * VEC - 1) / (16 * VEC);
-  const int kq = lane >> 4, j = lane & 15;
-  for (int pb = 0; pb < n_panels; pb += nwaves) {  // uniform over the workgroup
-    const int panel = pb + wave;
-    const int c = panel * 16 * VEC + j * VEC;
-    const bool cok = panel < n_panels && c < a.D;
-    f32x4 acc[VEC];
-#pragma unroll
-    for (int q = 0; q < VEC; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < K; k0 += kChunkK) {  // uniform
-      const int kc = min(kChunkK, K - k0);
-      __syncthreads();
-      for (int i = threadIdx.x; i < kChunkK; i += nthreads) s_U[i] = -1;
-      for (int i = threadIdx.x; i < kChunkK / 2; i += nthreads) s_mask[i] = 0u;
-      __syncthreads();
-      for (int e = lo + (int)threadIdx.x; e < hi; e += nthreads) {
-        const int cc = a.edgeToColumn[e] - k0;
-        if (cc >= 0 && cc < kc) {
-          const int rl = a.edgeToRow[e] - r0;
-          const int bit = 16 * (cc & 3) + rl;  // MFMA A-operand lane of (row rl, k = cc & 3)
-          atomicOr(&s_mask[(cc >> 2) * 2 + (bit >> 5)], 1u << (bit & 31));
-          s_U[cc] = a.col[e];
-        }
-      }
-      __syncthreads();
-      const int steps = (kc + 3) / 4;
-      for (int t0 = 0; t0 < steps; t0 += 4) {
-        vec_t x[4];
-        float av[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int t = t0 + u;
-          const bool tv = t < steps;
-          const int idx = tv ? s_U[min(4 * t + kq, kChunkK - 1)] : -1;
-          const unsigned int mw = tv ? s_mask[t * 2 + (lane >> 5)] : 0u;
-          av[u] = ((mw >> (lane & 31)) & 1u) ? 1.0f : 0.0f;
-          x[u] = vzero<VEC>();
-          if (cok && idx >= 0) x[u] = *reinterpret_cast<const vec_t*>(a.X + (size_t)idx * a.ldx + c);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-#pragma unroll
-          for (int q = 0; q < VEC; ++q)
-            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], vget(x[u], q), acc[q], 0, 0, 0);
-        }
-      }
-    }
-    if (cok) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = r0 + 4 * kq + r;
-        if (row < a.N) {
-          vec_t o;
-#pragma unroll
-          for (int q = 0; q < VEC; ++q) vset(o, q, acc[q][r]);
-          *reinterpret_cast<vec_t*>(a.Z + (size_t)row * a.ldz + c) = o;
-        }
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// Host-side dispatch on (L, VEC).
-// ------------------------------------------------------------------------------------------
-template <int L, int VEC>
-static hipError_t launch_plan_LV(const PlanArgs& a, hipStream_t stream) {
-  constexpr int R = 64 / L;
-  PlanArgs b = a;
-  b.n_wide = (R > 1) ? a.n_wide : 0;  // with one lane group per wave a wide task is an ordinary one
-  b.wide_wgs = (b.n_wide + kWaves - 1) / kWaves;
-  b.tiny_wgs = (a.n_tiny + kWaves * R * TinyT<L>::value - 1) / (kWaves * R * TinyT<L>::value);
-  b.sparse_wgs_pp = b.wide_wgs + (a.n_tasks - a.n_tiny - b.n_wide + kWaves * R - 1) / (kWaves * R) + b.tiny_wgs;
-  const int n_col_panels = (a.D + a.panel_cols - 1) / a.panel_cols;
-  b.sparse_wgs = b.sparse_wgs_pp * n_col_panels;
-  if (b.sparse_wgs_pp == 0) b.sparse_wgs_pp = 1;  // divisor in the kernel
-  // dense-tile panel width: 16*dense_vec columns -- never wider than the embedding (idle MFMA lanes)
-  b.dense_vec = (a.D >= 64) ? VEC : (a.D >= 32 ? (VEC < 2 ? VEC : 2) : 1);
-  if (b.dense_vec > VEC) b.dense_vec = VEC;
-  b.n_panels = (a.D + 16 * b.dense_vec - 1) / (16 * b.dense_vec);
-  const long long dense_units = (long long)a.n_dense * b.n_panels;
-  const long long dense_wgs = (dense_units + kWaves - 1) / kWaves;
-  const long long grid = (long long)b.sparse_wgs + dense_wgs;
-  if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
-  if (grid > 0) {
-    hipLaunchKernelGGL((hybrid_plan_kernel<L, VEC, HCSPMM_SPARSE_U, HCSPMM_MIN_WAVES_PER_SIMD>), dim3((unsigned)grid),
-                       dim3(kThreads), 0, stream, b);
-  }
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  if (a.n_split_rows > 0) {
-    const int fg = (a.n_split_rows + kWaves - 1) / kWaves;
-    hipLaunchKernelGGL((fixup_kernel<VEC>), dim3(fg), dim3(kThreads), 0, stream, b);
-    e = hipGetLastError();
-  }
-  return e;
-}
-
-template <int L, int VEC>
-static hipError_t launch_window_LV(const WindowArgs& a, hipStream_t stream) {
-  const int W = (a.N + 15) / 16;
-  // 16 rows x L lanes of sparse work, D/(16*VEC) dense panels: narrow embeddings get narrower workgroups
-  // (a 256-thread workgroup per window is dispatch-bound when each window holds a handful of entries)
-  const int n_panels = (a.D + 16 * VEC - 1) / (16 * VEC);
-  int waves = (16 * L + 63) / 64;
-  if (n_panels > waves) waves = n_panels;
-  if (waves > kWaves) waves = kWaves;
-  if (W > 0) hipLaunchKernelGGL((hybrid_window_kernel<L, VEC>), dim3(W), dim3(waves * 64), 0, stream, a);
-  return hipGetLastError();
-}
-
-// lanes per task: smallest power of two >= D / VEC, clamped to [4, 64]
-static int pick_L(int D, int VEC) {
-  const int slots = (D + VEC - 1) / VEC;
-  int L = 4;
-  while (L < slots && L < 64) L <<= 1;
-  return L;
-}
-
-#define HCSPMM_DISPATCH_L(FN, VEC, ARGS, STREAM)            \
-  switch (pick_L((ARGS).panel_cols, VEC)) {                 \
-    case 4:  return FN<4, VEC>(ARGS, STREAM);               \
-    case 8:  return FN<8, VEC>(ARGS, STREAM);               \
-    case 16: return FN<16, VEC>(ARGS, STREAM);              \
-    case 32: return FN<32, VEC>(ARGS, STREAM);              \
-    default: return FN<64, VEC>(ARGS, STREAM);              \
-  }
-
-hipError_t launch_plan(const PlanArgs& a, int vec, hipStream_t stream) {
-  if (vec == 4) { HCSPMM_DISPATCH_L(launch_plan_LV, 4, a, stream) }
-  if (vec == 2) { HCSPMM_DISPATCH_L(launch_plan_LV, 2, a, stream) }
-  HCSPMM_DISPATCH_L(launch_plan_LV, 1, a, stream)
-}
-
-#define HCSPMM_DISPATCH_LW(FN, VEC, ARGS, STREAM)           \
-  switch (pick_L((ARGS).D, VEC)) {                          \
-    case 4:  return FN<4, VEC>(ARGS, STREAM);               \
-    case 8:  return FN<8, VEC>(ARGS, STREAM);               \
-    case 16: return FN<16, VEC>(ARGS, STREAM);              \
-    case 32: return FN<32, VEC>(ARGS, STREAM);              \
-    default: return FN<64, VEC>(ARGS, STREAM);              \
-  }
-
-hipError_t launch_window(const WindowArgs& a, int vec, hipStream_t stream) {
-  if (vec == 4) { HCSPMM_DISPATCH_LW(launch_window_LV, 4, a, stream) }
-  if (vec == 2) { HCSPMM_DISPATCH_LW(launch_window_LV, 2, a, stream) }
-  HCSPMM_DISPATCH_LW(launch_window_LV, 1, a, stream)
+hipError_t launch_window_f32(const WindowArgs& a, int vec, hipStream_t stream) {
+  if (vec == 4) { HCSPMM_DISPATCH_L(launch_window_LV, F32, 4, a.D, a, stream) }
+  if (vec == 2) { HCSPMM_DISPATCH_L(launch_window_LV, F32, 2, a.D, a, stream) }
+  HCSPMM_DISPATCH_L(launch_window_LV, F32, 1, a.D, a, stream)
 }
 
 }  // namespace hcspmm

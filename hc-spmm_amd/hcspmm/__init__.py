@@ -77,11 +77,12 @@ def plan_header(row_nzr, num_nodes=None, num_edges=None):
     return h
 
 
-def wide_threshold(row_nzr, embedding_dim):
+def wide_threshold(row_nzr, embedding_dim, dtype=torch.float32):
     """Rows of the sparse path with more entries than this are summed by a whole wave (shuffle-tree
     combine) instead of one lane group in CSR order; see hcspmm_wide_threshold in include/hcspmm.h."""
     h = plan_header(row_nzr)
-    return int(lib().hcspmm_wide_threshold(ctypes.byref(h) if h is not None else None, int(embedding_dim)))
+    return int(lib().hcspmm_wide_threshold_typed(ctypes.byref(h) if h is not None else None, int(embedding_dim),
+                                                 _DTYPES[dtype]))
 
 
 def _ptr(t):
@@ -175,13 +176,17 @@ def _check_input(t, name):
 _VALIDATE = os.environ.get("HCSPMM_VALIDATE", "0") == "1"
 
 
+# feature element types of hcspmm_forward_typed (include/hcspmm.h HCSPMM_DTYPE_*)
+_DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
 def _graph_args(X, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, hybrid_type, row_nzr,
-                rect=False):
+                rect=False, dtypes=(torch.float32,)):
     for t, n in ((X, "input"), (row_pointers, "nodePointer"), (column_index, "edgeList"),
                  (blockPartition, "blockPartition"), (edgeToColumn, "edgeToColumn"), (edgeToRow, "edgeToRow")):
         _check_input(t, n)
-    if X.dtype != torch.float32 or X.dim() != 2:
-        raise RuntimeError("input must be a 2-D float32 tensor")
+    if X.dtype not in dtypes or X.dim() != 2:
+        raise RuntimeError("input must be a 2-D %s tensor" % " / ".join(str(d).replace("torch.", "") for d in dtypes))
     N = row_pointers.size(0) - 1
     E = column_index.size(0)
     D = X.size(1)
@@ -199,9 +204,9 @@ def _spmm(X, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow
           Z=None, rect=False):
     L = lib()
     N, E, D, h = _graph_args(X, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, hybrid_type,
-                             row_nzr, rect)
+                             row_nzr, rect, dtypes=tuple(_DTYPES))
     if Z is None:
-        Z = torch.empty((N, D), dtype=torch.float32, device=X.device)
+        Z = torch.empty((N, D), dtype=X.dtype, device=X.device)
     ws, ws_bytes = None, 0
     if h is not None:
         ws_bytes = int(L.hcspmm_workspace_bytes(ctypes.byref(h), D))
@@ -209,15 +214,17 @@ def _spmm(X, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow
             ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=X.device)
     stream = ctypes.c_void_p(torch.cuda.current_stream(X.device).cuda_stream)
     with torch.cuda.device(X.device):
-        check(L.hcspmm_forward(_ptr(X), _ptr(Z), _ptr(row_pointers), _ptr(column_index), _ptr(blockPartition),
-                               _ptr(edgeToColumn), _ptr(edgeToRow), _ptr(hybrid_type),
-                               _ptr(row_nzr) if h is not None else ctypes.c_void_p(0),
-                               ctypes.byref(h) if h is not None else None, N, E, D, _ptr(ws), ws_bytes, stream))
+        check(L.hcspmm_forward_typed(_ptr(X), D, _ptr(Z), D, _DTYPES[X.dtype], _ptr(row_pointers), _ptr(column_index),
+                                     _ptr(blockPartition), _ptr(edgeToColumn), _ptr(edgeToRow), _ptr(hybrid_type),
+                                     _ptr(row_nzr) if h is not None else ctypes.c_void_p(0),
+                                     ctypes.byref(h) if h is not None else None, N, E, D, _ptr(ws), ws_bytes, stream))
     return Z
 
 
 def forward(X, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, hybrid_type, row_nzr, col_nzr):
-    """HCSPMM.forward -> [A*X]  (hybrid_all.cpp:194-221; any embedding_dim)."""
+    """HCSPMM.forward -> [A*X]  (hybrid_all.cpp:194-221; any embedding_dim).  X may also be float16 / bfloat16
+    (the paper's half-precision variants, Table VII): rows are gathered as stored, summed in fp32 in the fp32
+    path's order and rounded once -- Z has X's dtype."""
     return [_spmm(X, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, hybrid_type, row_nzr, col_nzr)]
 
 
@@ -241,8 +248,8 @@ def forward_into(X, Z, row_pointers, column_index, blockPartition, edgeToColumn,
     for t, n in ((X, "input"), (Z, "output")):
         if not t.is_cuda:
             raise RuntimeError("%s must be a CUDA tensor" % n)
-        if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1 or t.stride(0) < t.size(1):
-            raise RuntimeError("%s must be a 2-D float32 view with unit inner stride" % n)
+        if t.dtype not in _DTYPES or t.dtype != X.dtype or t.dim() != 2 or t.stride(1) != 1 or t.stride(0) < t.size(1):
+            raise RuntimeError("%s must be a 2-D float32 / float16 / bfloat16 view with unit inner stride" % n)
     N, E, D = row_pointers.size(0) - 1, column_index.size(0), X.size(1)
     if Z.size(0) != N or Z.size(1) != D:
         raise RuntimeError("output must be [num_nodes, embedding_dim]")
@@ -254,10 +261,10 @@ def forward_into(X, Z, row_pointers, column_index, blockPartition, edgeToColumn,
             ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=X.device)
     stream = ctypes.c_void_p(torch.cuda.current_stream(X.device).cuda_stream)
     with torch.cuda.device(X.device):
-        check(L.hcspmm_forward_strided(_ptr(X), X.stride(0), _ptr(Z), Z.stride(0), _ptr(row_pointers),
-                                       _ptr(column_index), _ptr(blockPartition), _ptr(edgeToColumn), _ptr(edgeToRow),
-                                       _ptr(hybrid_type), _ptr(row_nzr) if h is not None else ctypes.c_void_p(0),
-                                       ctypes.byref(h) if h is not None else None, N, E, D, _ptr(ws), ws_bytes, stream))
+        check(L.hcspmm_forward_typed(_ptr(X), X.stride(0), _ptr(Z), Z.stride(0), _DTYPES[X.dtype], _ptr(row_pointers),
+                                     _ptr(column_index), _ptr(blockPartition), _ptr(edgeToColumn), _ptr(edgeToRow),
+                                     _ptr(hybrid_type), _ptr(row_nzr) if h is not None else ctypes.c_void_p(0),
+                                     ctypes.byref(h) if h is not None else None, N, E, D, _ptr(ws), ws_bytes, stream))
     return Z
 
 

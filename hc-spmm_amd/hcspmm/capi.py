@@ -44,6 +44,9 @@ SYMBOLS = {
     "hcspmm_plan_check": (_int, [_hp, _i64, _i64]),
     "hcspmm_workspace_bytes": (_sz, [_hp, _int]),
     "hcspmm_wide_threshold": (ctypes.c_int32, [_hp, _int]),
+    "hcspmm_wide_threshold_typed": (ctypes.c_int32, [_hp, _int, _int]),
+    "hcspmm_forward_typed": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _hp, _i64, _i64, _int, _vp,
+                                    _sz, _vp]),
     "hcspmm_forward": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _hp, _i64, _i64, _int, _vp, _sz, _vp]),
     "hcspmm_forward_strided": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _hp, _i64, _i64, _int, _vp, _sz,
                                       _vp]),

@@ -75,16 +75,27 @@ struct Call {
   void* stream;
 };
 
+// HCSPMM_DTYPE_* of a feature tensor, -1 if unsupported
+int feature_dtype(const torch::Tensor& t) {
+  switch (t.scalar_type()) {
+    case torch::kFloat: return HCSPMM_DTYPE_F32;
+    case torch::kHalf: return HCSPMM_DTYPE_F16;
+    case torch::kBFloat16: return HCSPMM_DTYPE_BF16;
+    default: return -1;
+  }
+}
+
 Call prepare(const torch::Tensor& input, const torch::Tensor& nodePointer, const torch::Tensor& edgeList,
              const torch::Tensor& blockPartition, const torch::Tensor& edgeToColumn, const torch::Tensor& edgeToRow,
-             const torch::Tensor& row_nzr) {
+             const torch::Tensor& row_nzr, bool allow_16bit = false) {
   CHECK_INPUT(input);
   CHECK_INPUT(nodePointer);
   CHECK_INPUT(edgeList);
   CHECK_INPUT(blockPartition);
   CHECK_INPUT(edgeToColumn);
   CHECK_INPUT(edgeToRow);
-  TORCH_CHECK(input.scalar_type() == torch::kFloat && input.dim() == 2, "input must be a 2-D float32 tensor");
+  TORCH_CHECK(input.dim() == 2 && (allow_16bit ? feature_dtype(input) >= 0 : input.scalar_type() == torch::kFloat),
+              allow_16bit ? "input must be a 2-D float32 / float16 / bfloat16 tensor" : "input must be a 2-D float32 tensor");
   TORCH_CHECK(nodePointer.scalar_type() == torch::kInt && edgeList.scalar_type() == torch::kInt,
               "nodePointer / edgeList must be int32");
   Call c;
@@ -95,7 +106,7 @@ Call prepare(const torch::Tensor& input, const torch::Tensor& nodePointer, const
   c.has_plan = lookup(row_nzr, c.N, c.E, &c.header);
   if (c.has_plan) {
     const size_t need = hcspmm_workspace_bytes(&c.header, c.D);
-    if (need) c.workspace = torch::empty({(int64_t)(need / 4)}, input.options());
+    if (need) c.workspace = torch::empty({(int64_t)(need / 4)}, input.options().dtype(torch::kFloat));
   }
   c.stream = (void*)c10::hip::getCurrentHIPStream(input.device().index()).stream();
   return c;
@@ -108,12 +119,13 @@ torch::Tensor run_spmm(const torch::Tensor& input, const torch::Tensor& nodePoin
                        const torch::Tensor& blockPartition, const torch::Tensor& edgeToColumn,
                        const torch::Tensor& edgeToRow, const torch::Tensor& hybrid_type,
                        const torch::Tensor& row_nzr) {
-  Call c = prepare(input, nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow, row_nzr);
+  // fp16 / bf16 features too (the paper's half-precision variants, Table VII): Z has the input's dtype
+  Call c = prepare(input, nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow, row_nzr, true);
   auto output = torch::empty({c.N, (int64_t)c.D}, input.options());  // reference K.cu:431-433
   const c10::DeviceGuard guard(input.device());
-  const int rc = hcspmm_forward(
-      input.data_ptr<float>(), output.data_ptr<float>(), iptr(nodePointer), iptr(edgeList), iptr(blockPartition),
-      iptr(edgeToColumn), iptr(edgeToRow), iptr(hybrid_type), c.has_plan ? iptr(row_nzr) : nullptr,
+  const int rc = hcspmm_forward_typed(
+      input.data_ptr(), c.D, output.data_ptr(), c.D, feature_dtype(input), iptr(nodePointer), iptr(edgeList),
+      iptr(blockPartition), iptr(edgeToColumn), iptr(edgeToRow), iptr(hybrid_type), c.has_plan ? iptr(row_nzr) : nullptr,
       c.has_plan ? &c.header : nullptr, c.N, c.E, c.D, c.workspace.defined() ? c.workspace.data_ptr() : nullptr,
       c.workspace.defined() ? (size_t)c.workspace.numel() * 4 : 0, c.stream);
   check_rc(rc, "forward");

@@ -43,7 +43,7 @@ extern "C" {
 #define HCSPMM_RULE_AS_SHIPPED 2     /* K.cu:262 literally: float used as bool */
 #define HCSPMM_RULE_MI355X 3         /* same two features, coefficients refit on MI355X with the paper's procedure
                                         against THIS library's two sub-paths (tools/refit_classifier.py,
-                                        profiles/r01/classifier_refit_v2.json) at embedding width 32: for
+                                        profiles/r01/classifier_refit_v3.json) at embedding width 32: for
                                         narrow embeddings (D < 64); not a reference output */
 #define HCSPMM_RULE_MI355X_WIDE 4    /* the same refit at embedding width 128: for D >= 64 (preprocess does not
                                         know D -- the reference's signature has none -- so the caller picks) */
@@ -187,6 +187,27 @@ int hcspmm_forward_strided(const float* X_d, int64_t ldx, float* Z_d, int64_t ld
                            const int32_t* plan_d, const hcspmm_plan_header* plan_header_h, int64_t num_nodes,
                            int64_t num_edges, int embedding_dim, void* workspace_d, size_t workspace_bytes,
                            void* stream);
+
+/* Feature element types of hcspmm_forward_typed. */
+#define HCSPMM_DTYPE_F32 0
+#define HCSPMM_DTYPE_F16 1  /* IEEE binary16 */
+#define HCSPMM_DTYPE_BF16 2 /* bfloat16 */
+
+/* The same product for fp32, fp16 or bf16 features (the half-precision variants of the paper's Table VII, p.16;
+ * the reference repository ships fp32 only).  X and Z hold `dtype` elements, ldx / ldz count elements.  16-bit
+ * rows are gathered as stored (half the bytes of the fp32 path -- the launch is bound by exactly those bytes),
+ * widened exactly, summed in fp32 in the same order as the fp32 path, and rounded once (to nearest even) per
+ * output element:  Z = round_dtype(fp32 sum).  The workspace is fp32 whatever the dtype
+ * (hcspmm_workspace_bytes).  dtype = HCSPMM_DTYPE_F32 is hcspmm_forward_strided. */
+int hcspmm_forward_typed(const void* X_d, int64_t ldx, void* Z_d, int64_t ldz, int dtype,
+                         const int32_t* row_pointers_d, const int32_t* column_index_d,
+                         const int32_t* blockPartition_d, const int32_t* edgeToColumn_d, const int32_t* edgeToRow_d,
+                         const int32_t* hybrid_type_d, const int32_t* plan_d, const hcspmm_plan_header* plan_header_h,
+                         int64_t num_nodes, int64_t num_edges, int embedding_dim, void* workspace_d,
+                         size_t workspace_bytes, void* stream);
+
+/* hcspmm_wide_threshold for a feature type (lanes per row, hence the threshold, depend on the element size). */
+int32_t hcspmm_wide_threshold_typed(const hcspmm_plan_header* header_h, int embedding_dim, int dtype);
 
 /* ------------------------------------------------------------------------------------------
  * Fused aggregate + update: out2 = A * X (N x D), out = out2 * weights (N x H), weights row-major

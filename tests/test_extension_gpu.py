@@ -67,6 +67,13 @@ def test_extension_forward_and_fused(HCSPMM, oracle_mod, D):
     # a cloned plan tensor (unknown pointer) is recognised by its header
     assert np.array_equal(HCSPMM.forward(Xd, rp_d, col_d, outs[0], outs[1], outs[2], outs[3], outs[4].clone(),
                                          outs[5])[0].cpu().numpy(), ref)
+    # half-precision features (paper Table VII): same module functions, Z in the input's dtype
+    for dt in (torch.float16, torch.bfloat16):
+        X16 = Xd.to(dt)
+        out16 = HCSPMM.forward(X16, rp_d, col_d, *outs)[0]
+        assert out16.dtype == dt
+        want16 = torch.from_numpy(oracle_mod.spmm_f32(rp, col, X16.float().cpu().numpy())).to(dt)
+        assert torch.equal(out16.cpu().view(torch.int16), want16.view(torch.int16))  # no wide / split rows in this graph
     H = 16
     W = rng.standard_normal((D, H)).astype(np.float32)
     Wd = torch.from_numpy(W).to(dev)

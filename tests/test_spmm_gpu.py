@@ -205,6 +205,78 @@ def test_dense_windows_around_the_compact_record_limit(oracle_mod, dev, D):
     _check(oracle_mod, g, X, g.forward(_t(X, dev)), exact_bits=True)
 
 
+_H16_GRAPHS = [
+    ("powerlaw", lambda: graphs.powerlaw_graph(2000, 40000, seed=31, max_degree_frac=0.3)),   # wide + split rows
+    ("planted", lambda: graphs.planted_dense_graph(1500, seed=32)),                            # compact dense windows
+    ("uniform", lambda: graphs.uniform_graph(1003, 9000, seed=33)),                            # N % 16 != 0
+    ("tiny", lambda: _tiny_graph()),
+]
+
+
+def _check_h16(oracle_mod, g, X16, Z16):
+    """16-bit features: Z = round_dtype(fp32 sum in the fp32 path's order).  Bit-identical to the rounded CSR-order
+    fp32 oracle on every row that is summed sequentially; elsewhere within 1e-5 * sum|x| of the fp64 product plus one
+    rounding of the result."""
+    dtype = X16.dtype
+    assert Z16.dtype == dtype
+    Xf = X16.float().cpu().numpy()
+    D = Xf.shape[1]
+    ref32 = oracle_mod.spmm_f32(g.rp, g.col, Xf)
+    want = torch.from_numpy(ref32).to(dtype)  # torch rounds to nearest even, like the kernel
+    h = hcspmm.plan_header(g.row_nzr)
+    deg = np.diff(g.rp)
+    thr = hcspmm.wide_threshold(g.row_nzr, D, dtype)
+    seq = deg <= (thr if h is None else min(h.split_threshold, thr))
+    seq |= np.repeat(g.ht.cpu().numpy() != 0, 16)[:g.N]
+    got = Z16.cpu()
+    assert torch.equal(got[torch.from_numpy(seq)].view(torch.int16), want[torch.from_numpy(seq)].view(torch.int16))
+    ref64 = oracle_mod.spmm_f64(g.rp, g.col, Xf)
+    mag = oracle_mod.spmm_f64(g.rp, g.col, Xf, absolute=True)
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -10
+    assert np.all(np.abs(got.double().numpy() - ref64) <= 1e-5 * mag + eps * np.abs(ref64) + 1e-30)
+    return seq
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("D", [256, 128, 64, 40, 32, 20, 7])
+@pytest.mark.parametrize("name,gen", _H16_GRAPHS, ids=[g[0] for g in _H16_GRAPHS])
+def test_half_precision_features_planned(oracle_mod, dev, name, gen, D, dtype):
+    rp, col = gen()
+    g = Graph(rp, col, dev)
+    X16 = torch.from_numpy(np.random.default_rng(D).standard_normal((g.N, D)).astype(np.float32)).to(dtype).to(dev)
+    seq = _check_h16(oracle_mod, g, X16, g.forward(X16))
+    assert seq.any()
+    # integer-valued features small enough for the format: exact whatever the order
+    Xi = ((torch.arange(g.N)[:, None] + torch.arange(D)[None, :]) % 4).to(dtype).to(dev)
+    Zi = g.forward(Xi).float().cpu().numpy()
+    assert np.array_equal(Zi, torch.from_numpy(oracle_mod.spmm_f32(rp, col, Xi.float().cpu().numpy())).to(dtype).float().numpy())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("D", [128, 24, 5])
+@pytest.mark.parametrize("mode", ["plan_free", "all_dense", "all_sparse"])
+def test_half_precision_features_other_paths(oracle_mod, dev, D, dtype, mode):
+    rp, col = graphs.powerlaw_graph(1500, 20000, seed=41, max_degree_frac=0.2)
+    g = Graph(rp, col, dev, plan=(mode != "plan_free"), force_type={"all_dense": 1, "all_sparse": 0}.get(mode))
+    X16 = torch.from_numpy(np.random.default_rng(7).standard_normal((g.N, D)).astype(np.float32)).to(dtype).to(dev)
+    _check_h16(oracle_mod, g, X16, g.forward(X16))
+
+
+def test_half_precision_strided_views_and_errors(oracle_mod, dev):
+    rp, col = graphs.powerlaw_graph(900, 12000, seed=43)
+    g = Graph(rp, col, dev)
+    wide = torch.randn(g.N, 192, device=dev).to(torch.bfloat16)
+    out = torch.zeros(g.N, 192, dtype=torch.bfloat16, device=dev)
+    hcspmm.forward_into(wide[:, 64:128], out[:, 128:192], *g.args())
+    assert torch.equal(out[:, 128:192], g.forward(wide[:, 64:128].contiguous())) and not out[:, :128].any()
+    with pytest.raises(RuntimeError, match="float32 / float16 / bfloat16"):
+        hcspmm.forward_into(wide[:, :64], torch.zeros(g.N, 64, device=dev), *g.args())  # mixed dtypes
+    with pytest.raises(RuntimeError, match="float32"):
+        g.forward(torch.zeros(g.N, 8, dtype=torch.float64, device=dev))
+    with pytest.raises(RuntimeError, match="float32"):  # the fused update stays fp32
+        hcspmm.forward_fixed32_fused(wide[:, :32].contiguous(), *g.args(), torch.zeros(32, 8, device=dev))
+
+
 def _tiny_graph(N=3000, seed=9):
     """Mostly rows of 0, 1 and 2 entries (the descriptors that carry their indices inline), a sprinkling of
     longer ones, and hub rows of 513 / 514 / 770 entries whose LAST segment has 1 / 2 / 2 entries."""

@@ -135,6 +135,14 @@ template <typename E, int VEC> struct Lane {
   }
 };
 
+// The plan is read-only for the whole launch.  Wave-uniform reads of it (dense index entries, tile masks) go
+// through the constant address space so that they are scalar loads (s_load_*) whatever the surrounding
+// control flow: when that was left to the compiler's no-clobber analysis, adding the compact-record branch
+// silently turned them into vector loads and cost the regular dense units 16 % (profiles/r01/ab_scalar_masks.log).
+#define HCSPMM_CONST_AS __attribute__((address_space(4)))
+typedef const HCSPMM_CONST_AS int* cint_p;
+typedef const HCSPMM_CONST_AS unsigned long long* cu64_p;
+
 constexpr int kWaves = 4;            // waves per workgroup (256 threads)
 constexpr int kThreads = kWaves * 64;
 #ifndef HCSPMM_SPARSE_U
@@ -337,9 +345,8 @@ __device__ __forceinline__ void dense_store(typename E::T* __restrict__ Z, const
 
 template <typename E, int VEC>
 __device__ __forceinline__ void dense_unit(const typename E::T* __restrict__ X, typename E::T* __restrict__ Z,
-                                           const int* __restrict__ U, const unsigned long long* __restrict__ masks,
-                                           int K4, int window, int panel, int N, int D, size_t ldx, size_t ldz,
-                                           int lane) {
+                                           const int* __restrict__ U, cu64_p masks, int K4, int window, int panel,
+                                           int N, int D, size_t ldx, size_t ldz, int lane) {
   typedef Lane<E, VEC> Ln;
   const int kq = lane >> 4, j = lane & 15;
   const int c = panel * 16 * VEC + j * VEC;
@@ -514,9 +521,10 @@ __global__ __launch_bounds__(kThreads, MINW) void hybrid_plan_kernel(PlanArgs a)
       return;
     }
     const int panel = unit / n_reg, di = unit - panel * n_reg;  // panel-major, like the sparse region
-    const int4 d = reinterpret_cast<const int4*>(a.plan + a.off_dense_index)[di];
+    cint_p dix = (cint_p)(a.plan + a.off_dense_index) + 4 * di;  // wave-uniform: scalar loads
+    const int4 d = int4{dix[0], dix[1], dix[2], dix[3]};
     const int* U = a.plan + a.off_dense_pack + d.y;
-    const unsigned long long* masks = reinterpret_cast<const unsigned long long*>(U + 4 * d.z);
+    cu64_p masks = (cu64_p)(U + 4 * d.z);
     if (a.dense_vec == VEC) dense_unit<E, VEC>(X, Z, U, masks, d.z, d.x, panel, a.N, a.D, a.ldx, a.ldz, lane);
     else if (a.dense_vec == VM) dense_unit<E, VM>(X, Z, U, masks, d.z, d.x, panel, a.N, a.D, a.ldx, a.ldz, lane);
     else dense_unit<E, 1>(X, Z, U, masks, d.z, d.x, panel, a.N, a.D, a.ldx, a.ldz, lane);

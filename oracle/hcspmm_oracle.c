@@ -71,10 +71,10 @@ int32_t hcspmm_oracle_classify(int32_t size, uint32_t nnz_window, int32_t num, i
     volatile float dens = (float)nnz_window / (float)(num * BLK_H * BLK_W);
     int wide = rule == RULE_MI355X_WIDE, compact = num * BLK_W <= 32;
     double w1 = 0.0, w2, b;
-    if (!wide && compact) { w2 = -30.904771063924702; b = 3.2248272656712498; }
+    if (!wide && compact) { w2 = -30.904771063924702; b = 2.163333974474729; }
     else if (!wide) { w2 = -91.39571130769644; b = 18.406719120321213; }
     else if (compact) { w2 = -39.36167079949795; b = -0.21260854261350828; }
-    else { w1 = 0.08953178072727347; w2 = -46.44063869582706; b = -6.402170211696355; }
+    else { w1 = 0.030703533058157952; w2 = -139.72170588602881; b = 4.259271957775277; }
     volatile double a1 = (double)((float)size) * w1;
     volatile double a2 = (double)dens * w2;
     volatile double z = a1 + a2;

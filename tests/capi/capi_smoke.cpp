@@ -110,6 +110,38 @@ int main() {
         return 5;
       }
   }
+  // bfloat16 features through hcspmm_forward_typed: 16-bit X and Z, fp32 accumulation, one rounding (to nearest
+  // even) per output element.  The features are small integers (exact in bf16), so the fp32 sum is exact and
+  // the expected output is simply the rounded `want`.
+  {
+    auto to_bf16 = [](float f) {
+      uint32_t u;
+      std::memcpy(&u, &f, 4);
+      u += 0x7fffu + ((u >> 16) & 1u);
+      return (uint16_t)(u >> 16);
+    };
+    std::vector<uint16_t> X16(X.size()), got16(X.size());
+    for (size_t i = 0; i < X.size(); ++i) X16[i] = to_bf16(X[i]);
+    uint16_t* X16_d = upload(X16);
+    uint16_t* Z16_d = nullptr;
+    HIP_OK(hipMalloc(&Z16_d, sizeof(uint16_t) * X.size()));
+    for (int pass = 0; pass < 2; ++pass) {
+      HIP_OK(hipMemsetAsync(Z16_d, 0xff, sizeof(uint16_t) * X.size(), stream));
+      HC_OK(hcspmm_forward_typed(X16_d, D, Z16_d, D, HCSPMM_DTYPE_BF16, rp_d, col_d, bp_d, e2c_d, e2r_d, ht_d,
+                                 pass == 0 ? plan_d : nullptr, pass == 0 ? &header : nullptr, N, E, D,
+                                 pass == 0 ? ws_d : nullptr, pass == 0 ? ws_bytes : 0, (void*)stream));
+      HIP_OK(hipMemcpyAsync(got16.data(), Z16_d, sizeof(uint16_t) * got16.size(), hipMemcpyDeviceToHost, stream));
+      HIP_OK(hipStreamSynchronize(stream));
+      for (size_t i = 0; i < got16.size(); ++i)
+        if (got16[i] != to_bf16(want[i])) {
+          std::fprintf(stderr, "bf16 pass %d mismatch at %zu: %04x vs %04x\n", pass, i, got16[i], to_bf16(want[i]));
+          return 8;
+        }
+    }
+    if (hcspmm_forward_typed(X16_d, D, Z16_d, D, 7, rp_d, col_d, bp_d, e2c_d, e2r_d, ht_d, plan_d, &header, N, E, D, ws_d,
+                             ws_bytes, stream) != HCSPMM_EINVAL)
+      return 9;
+  }
   // argument errors come back as codes, not crashes
   if (hcspmm_forward(X_d, Z_d, rp_d, col_d, bp_d, e2c_d, e2r_d, ht_d, plan_d, &header, N + 1, E, D, ws_d, ws_bytes, stream) !=
       HCSPMM_EPLAN)

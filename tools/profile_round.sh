@@ -15,9 +15,12 @@ run() {  # name, bench args...
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/$name/mfma -- python3 bench.py "$@" --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
   echo "$name done"
 }
-mkdir -p $OUT/reddit_d128 $OUT/alldense_d128 $OUT/dense_d128 $OUT/reddit_d32 $OUT/reddit_d256
+for n in reddit_d128 alldense_d128 dense_d128 reddit_d32 reddit_d256 rd_like_d32 yh_like_d32 reddit_d128_bf16; do mkdir -p $OUT/$n; done
 run reddit_d128
 run alldense_d128 --workload alldense
 run dense_d128 --workload dense
 run reddit_d32 --dim 32
 run reddit_d256 --dim 256
+run rd_like_d32 --workload rd_like
+run yh_like_d32 --workload yh_like
+run reddit_d128_bf16 --dtype bf16

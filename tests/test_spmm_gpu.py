@@ -269,6 +269,12 @@ def test_half_precision_strided_views_and_errors(oracle_mod, dev):
     out = torch.zeros(g.N, 192, dtype=torch.bfloat16, device=dev)
     hcspmm.forward_into(wide[:, 64:128], out[:, 128:192], *g.args())
     assert torch.equal(out[:, 128:192], g.forward(wide[:, 64:128].contiguous())) and not out[:, :128].any()
+    # views whose first element is only 8-byte / 2-byte aligned: the 4- and 1-element-per-lane builds
+    for off in (4, 1):
+        out.zero_()
+        hcspmm.forward_into(wide[:, off:off + 64], out[:, off:off + 64], *g.args())
+        assert torch.equal(out[:, off:off + 64], g.forward(wide[:, off:off + 64].contiguous()))
+        assert not out[:, :off].any() and not out[:, off + 64:].any()
     with pytest.raises(RuntimeError, match="float32 / float16 / bfloat16"):
         hcspmm.forward_into(wide[:, :64], torch.zeros(g.N, 64, device=dev), *g.args())  # mixed dtypes
     with pytest.raises(RuntimeError, match="float32"):

@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "hcspmm.h"
@@ -108,6 +109,22 @@ extern "C" int hcspmm_plan_words(const int32_t* rowptr, int64_t N, int64_t E, co
   return HCSPMM_OK;
 }
 
+// power-of-two length class: 0 -> 0, 1 -> 1, 2 -> 2, 3..4 -> 3, 5..8 -> 4, 9..16 -> 5, 17..32 -> 6, ...
+static inline int length_class(int32_t len) {
+  int c = 0;
+  while (len > 0) { ++c; len = (len == 1) ? 0 : (len + 1) / 2; }
+  return c;
+}
+
+// Runs fn(t) for t in [0, T) on T threads (T == 1: inline).
+template <typename F> static void parallel_for(int T, F fn) {
+  if (T <= 1) { fn(0); return; }
+  std::vector<std::thread> th;
+  th.reserve((size_t)T);
+  for (int t = 0; t < T; ++t) th.emplace_back(fn, t);
+  for (auto& x : th) x.join();
+}
+
 extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const int32_t* bp,
                                  const int32_t* e2c, const int32_t* ht, const hcspmm_plan_params* params,
                                  int32_t* plan, int64_t words) {
@@ -119,119 +136,181 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
   int rc = compute_layout(rowptr, N, bp, ht, rp, &L);
   if (rc != HCSPMM_OK) return rc;
   if (words < L.total) return HCSPMM_EINVAL;
-  std::memset(plan, 0, sizeof(int32_t) * (size_t)L.total);
   const int64_t W = (N + HCSPMM_BLK_H - 1) / HCSPMM_BLK_H;
 
-  // ---- sparse tasks: collect, then counting-sort by descending length (stable in row order)
-  struct Task { int32_t row, e0, len, slot; };
-  std::vector<Task> tasks;
-  tasks.reserve((size_t)L.n_tasks);
-  int32_t* fix = plan + L.off_fixups;
-  int64_t n_fix = 0, slot = 0;
-  struct DenseRef { int32_t w, K; };
-  std::vector<DenseRef> dense;
-  dense.reserve((size_t)L.n_dense);
-  for (int64_t w = 0; w < W; ++w) {
-    const int64_t r0 = w * HCSPMM_BLK_H, r1 = std::min<int64_t>(r0 + HCSPMM_BLK_H, N);
-    const int64_t nnz = (int64_t)rowptr[r1] - rowptr[r0];
-    if (ht[w] != 0 && nnz > 0) {
-      dense.push_back({(int32_t)w, bp[w] * HCSPMM_BLK_W});
-      continue;
-    }
-    for (int64_t r = r0; r < r1; ++r) {
-      const int32_t e0 = rowptr[r];
-      const int64_t d = (int64_t)rowptr[r + 1] - e0;
-      if (d > rp.split_threshold) {
-        const int64_t segs = (d + rp.segment_len - 1) / rp.segment_len;
-        fix[4 * n_fix + 0] = (int32_t)r;
-        fix[4 * n_fix + 1] = (int32_t)slot;
-        fix[4 * n_fix + 2] = (int32_t)segs;
-        ++n_fix;
-        for (int64_t s = 0; s < segs; ++s) {
-          const int64_t b = s * rp.segment_len;
-          tasks.push_back({(int32_t)r, (int32_t)(e0 + b), (int32_t)std::min<int64_t>(rp.segment_len, d - b),
-                           (int32_t)slot++});
-        }
-      } else {
-        tasks.push_back({(int32_t)r, e0, (int32_t)d, -1});
-      }
-    }
+  // Threads work on contiguous window ranges; every output position follows from per-thread counts in
+  // range order, so the blob is identical for any thread count.
+  int T = std::min(64, (int)std::thread::hardware_concurrency());
+  if (T < 1 || W < 4096) T = 1;
+  std::vector<int64_t> cut((size_t)T + 1);
+  for (int t = 0; t <= T; ++t) cut[(size_t)t] = W * t / T;
+  {  // zero the blob (padding, masks) in parallel: it is tens of MB for a multi-million-row graph
+    std::vector<int64_t> zc((size_t)T + 1);
+    for (int t = 0; t <= T; ++t) zc[(size_t)t] = L.total * t / T;
+    parallel_for(T, [&](int t) {
+      std::memset(plan + zc[(size_t)t], 0, sizeof(int32_t) * (size_t)(zc[(size_t)t + 1] - zc[(size_t)t]));
+    });
   }
-  // Order: by descending power-of-two length class (0, 1, 2, 3-4, 5-8, 9-16, ...), rows ascending
-  // inside a class.  Classes keep the lane groups of a wave within 2x of each other and put the
+
+  // ---- sparse tasks.  Order: by descending power-of-two length class (0, 1, 2, 3-4, 5-8, 9-16, ...), rows
+  // ascending inside a class.  Classes keep the lane groups of a wave within 2x of each other and put the
   // heavy work first; row order inside a class keeps the Z stores, the column-index reads and the
   // task reads of neighbouring waves close together in memory (a full sort by length scatters them,
   // which costs a few % on low-degree graphs where X and Z live in HBM, not in the Infinity Cache;
   // merging all rows <= 16 entries into ONE row-ordered class is worse, profiles/r01/ab_merge_short.log).
-  int32_t len_gt[5] = {0, 0, 0, 0, 0};
-  int64_t n_tiny = 0;
-  {
-    auto cls = [](int32_t len) {  // 0 -> 0, 1 -> 1, 2 -> 2, 3..4 -> 3, 5..8 -> 4, 9..16 -> 5, 17..32 -> 6, ...
-      int c = 0;
-      while (len > 0) { ++c; len = (len == 1) ? 0 : (len + 1) / 2; }
-      return c;
-    };
-    const int n_cls = cls(rp.split_threshold) + 1;
-    std::vector<int64_t> start((size_t)n_cls + 1, 0);
-    for (const Task& t : tasks) start[(size_t)(n_cls - 1 - cls(t.len)) + 1]++;  // bucket 0 = longest class
-    for (size_t i = 1; i < start.size(); ++i) start[i] += start[i - 1];
-    for (int b = 0; b < 5; ++b) {  // prefix sizes: tasks longer than 16 << b  (class boundaries are powers of two)
-      const int c = cls((16 << b) + 1);  // first class whose members are all > 16 << b
-      len_gt[b] = c >= n_cls ? 0 : (int32_t)start[(size_t)(n_cls - c)];
-    }
-    int32_t* out = plan + L.off_tasks;
-    for (const Task& t : tasks) {
-      const int64_t p = start[(size_t)(n_cls - 1 - cls(t.len))]++;
-      if (t.len <= HCSPMM_TINY_LEN) {  // classes 2, 1, 0: the tail of the list
-        ++n_tiny;
-        out[4 * p + 0] = t.slot < 0 ? t.row : -(t.slot + 1);
-        out[4 * p + 1] = t.len >= 1 ? col[t.e0] : -1;
-        out[4 * p + 2] = t.len;
-        out[4 * p + 3] = t.len >= 2 ? col[t.e0 + 1] : -1;
+  // Pass 1 counts per (thread, class); pass 2 writes every task straight to its final slot.
+  const int n_cls = length_class(rp.split_threshold) + 1;
+  struct Counts {
+    std::vector<int64_t> cls;
+    int64_t n_fix = 0, n_slots = 0, n_dense = 0;
+  };
+  std::vector<Counts> cnt((size_t)T);
+  auto walk = [&](int t, auto&& on_task, auto&& on_fix, auto&& on_dense) {
+    for (int64_t w = cut[(size_t)t]; w < cut[(size_t)t + 1]; ++w) {
+      const int64_t r0 = w * HCSPMM_BLK_H, r1 = std::min<int64_t>(r0 + HCSPMM_BLK_H, N);
+      const int64_t nnz = (int64_t)rowptr[r1] - rowptr[r0];
+      if (ht[w] != 0 && nnz > 0) {
+        on_dense(w);
         continue;
       }
-      out[4 * p + 0] = t.row;
-      out[4 * p + 1] = t.e0;
-      out[4 * p + 2] = t.len;
-      out[4 * p + 3] = t.slot;
+      for (int64_t r = r0; r < r1; ++r) {
+        const int32_t e0 = rowptr[r];
+        const int64_t d = (int64_t)rowptr[r + 1] - e0;
+        if (d > rp.split_threshold) {
+          const int64_t segs = (d + rp.segment_len - 1) / rp.segment_len;
+          const int64_t slot0 = on_fix(r, segs);
+          for (int64_t sgm = 0; sgm < segs; ++sgm) {
+            const int64_t b = sgm * rp.segment_len;
+            on_task((int32_t)r, (int32_t)(e0 + b), (int32_t)std::min<int64_t>(rp.segment_len, d - b), (int32_t)(slot0 + sgm));
+          }
+        } else {
+          on_task((int32_t)r, e0, (int32_t)d, -1);
+        }
+      }
+    }
+  };
+  parallel_for(T, [&](int t) {
+    Counts& c = cnt[(size_t)t];
+    c.cls.assign((size_t)n_cls, 0);
+    walk(t, [&](int32_t, int32_t, int32_t len, int32_t) { c.cls[(size_t)length_class(len)]++; },
+         [&](int64_t, int64_t segs) { c.n_fix++; c.n_slots += segs; return (int64_t)0; },
+         [&](int64_t) { c.n_dense++; });
+  });
+  // class starts (bucket 0 = longest class), then per-thread offsets inside each class, in range order
+  std::vector<int64_t> start((size_t)n_cls + 1, 0);
+  for (int c = 0; c < n_cls; ++c) {
+    int64_t tot = 0;
+    for (int t = 0; t < T; ++t) tot += cnt[(size_t)t].cls[(size_t)c];
+    start[(size_t)(n_cls - 1 - c) + 1] = tot;
+  }
+  for (size_t i = 1; i < start.size(); ++i) start[i] += start[i - 1];
+  int32_t len_gt[5] = {0, 0, 0, 0, 0};
+  for (int b = 0; b < 5; ++b) {  // prefix sizes: tasks longer than 16 << b  (class boundaries are powers of two)
+    const int c = length_class((16 << b) + 1);  // first class whose members are all > 16 << b
+    len_gt[b] = c >= n_cls ? 0 : (int32_t)start[(size_t)(n_cls - c)];
+  }
+  int64_t n_tiny = 0;
+  for (int c = 0; c <= length_class(HCSPMM_TINY_LEN) && c < n_cls; ++c)
+    for (int t = 0; t < T; ++t) n_tiny += cnt[(size_t)t].cls[(size_t)c];
+  std::vector<std::vector<int64_t>> pos((size_t)T, std::vector<int64_t>((size_t)n_cls));
+  std::vector<int64_t> fix_at((size_t)T + 1, 0), slot_at((size_t)T + 1, 0), dense_at((size_t)T + 1, 0);
+  {
+    std::vector<int64_t> run(start.begin(), start.end() - 1);  // next free slot per bucket
+    for (int t = 0; t < T; ++t) {
+      for (int c = 0; c < n_cls; ++c) {
+        pos[(size_t)t][(size_t)c] = run[(size_t)(n_cls - 1 - c)];
+        run[(size_t)(n_cls - 1 - c)] += cnt[(size_t)t].cls[(size_t)c];
+      }
+      fix_at[(size_t)t + 1] = fix_at[(size_t)t] + cnt[(size_t)t].n_fix;
+      slot_at[(size_t)t + 1] = slot_at[(size_t)t] + cnt[(size_t)t].n_slots;
+      dense_at[(size_t)t + 1] = dense_at[(size_t)t] + cnt[(size_t)t].n_dense;
     }
   }
+  if (fix_at[(size_t)T] != L.n_split_rows || slot_at[(size_t)T] != L.n_partials || dense_at[(size_t)T] != L.n_dense ||
+      start.back() != L.n_tasks)
+    return HCSPMM_EINVAL;  // (cannot happen: compute_layout counted the same things)
+  struct DenseRef { int32_t w, K; };
+  std::vector<DenseRef> dense((size_t)L.n_dense);
+  int32_t* out = plan + L.off_tasks;
+  int32_t* fix = plan + L.off_fixups;
+  parallel_for(T, [&](int t) {
+    std::vector<int64_t>& p = pos[(size_t)t];
+    int64_t n_fix = fix_at[(size_t)t], slot = slot_at[(size_t)t], nd = dense_at[(size_t)t];
+    walk(t,
+         [&](int32_t row, int32_t e0, int32_t len, int32_t slot_id) {
+           const int64_t q = p[(size_t)length_class(len)]++;
+           if (len <= HCSPMM_TINY_LEN) {  // classes 2, 1, 0: the tail of the list
+             out[4 * q + 0] = slot_id < 0 ? row : -(slot_id + 1);
+             out[4 * q + 1] = len >= 1 ? col[e0] : -1;
+             out[4 * q + 2] = len;
+             out[4 * q + 3] = len >= 2 ? col[e0 + 1] : -1;
+           } else {
+             out[4 * q + 0] = row;
+             out[4 * q + 1] = e0;
+             out[4 * q + 2] = len;
+             out[4 * q + 3] = slot_id;
+           }
+         },
+         [&](int64_t r, int64_t segs) {
+           fix[4 * n_fix + 0] = (int32_t)r;
+           fix[4 * n_fix + 1] = (int32_t)slot;
+           fix[4 * n_fix + 2] = (int32_t)segs;
+           ++n_fix;
+           const int64_t s0 = slot;
+           slot += segs;
+           return s0;
+         },
+         [&](int64_t w) { dense[(size_t)nd++] = DenseRef{(int32_t)w, bp[w] * HCSPMM_BLK_W}; });
+  });
 
-  // ---- dense windows: widest first; pack U and the MFMA lane masks
+  // ---- dense windows: widest first (stable, so window order inside a width); pack U and the MFMA lane masks
   std::stable_sort(dense.begin(), dense.end(), [](const DenseRef& a, const DenseRef& b) { return a.K > b.K; });
   int32_t* dindex = plan + L.off_dense_index;
   int32_t* dpack = plan + L.off_dense_pack;
-  int64_t pack_off = 0, uniq_total = 0, n_compact_done = 0;
-  for (size_t i = 0; i < dense.size(); ++i) {
-    const int64_t w = dense[i].w;
-    const int32_t K = dense[i].K, K4 = K / 4;
-    const int64_t r0 = w * HCSPMM_BLK_H, r1 = std::min<int64_t>(r0 + HCSPMM_BLK_H, N);
-    const bool compact = K <= HCSPMM_COMPACT_K;  // sorted by K: the compact windows are the tail of the list
-    int32_t* rec = plan + L.off_compact + HCSPMM_COMPACT_WORDS * n_compact_done;
-    int32_t* U = compact ? rec + 2 : dpack + pack_off;
-    // little-endian halves of the 64-bit masks
-    uint32_t* masks = reinterpret_cast<uint32_t*>(compact ? rec + 2 + HCSPMM_COMPACT_K : U + K);
-    if (compact) {
-      rec[0] = (int32_t)w;
-      rec[1] = K4;
-    }
-    for (int32_t k = 0; k < (compact ? HCSPMM_COMPACT_K : K); ++k) U[k] = -1;
-    for (int64_t r = r0; r < r1; ++r) {
-      for (int64_t e = rowptr[r]; e < rowptr[r + 1]; ++e) {
-        const int32_t c = e2c[e];
-        if (c < 0 || c >= K) return HCSPMM_EINVAL;
-        U[c] = col[e];
-        const int lane = 16 * (c & 3) + (int)(r - r0);
-        masks[(c >> 2) * 2 + (lane >> 5)] |= 1u << (lane & 31);
+  const int64_t n_reg = L.n_dense - L.n_compact;  // sorted by K: the compact windows are the tail of the list
+  std::vector<int64_t> pack_at((size_t)n_reg + 1, 0);
+  for (int64_t i = 0; i < n_reg; ++i) pack_at[(size_t)i + 1] = pack_at[(size_t)i] + dense[(size_t)i].K + (dense[(size_t)i].K / 4) * 2;
+  std::vector<int64_t> uniq_part((size_t)T, 0);
+  std::vector<int> bad((size_t)T, 0);
+  parallel_for(T, [&](int t) {
+    int64_t uniq_total = 0;
+    for (int64_t i = L.n_dense * t / T; i < L.n_dense * (t + 1) / T; ++i) {
+      const int64_t w = dense[(size_t)i].w;
+      const int32_t K = dense[(size_t)i].K, K4 = K / 4;
+      const int64_t r0 = w * HCSPMM_BLK_H, r1 = std::min<int64_t>(r0 + HCSPMM_BLK_H, N);
+      const bool compact = i >= n_reg;
+      if (compact != (K <= HCSPMM_COMPACT_K)) { bad[(size_t)t] = 1; return; }
+      const int64_t off = compact ? HCSPMM_COMPACT_WORDS * (i - n_reg) : pack_at[(size_t)i];
+      int32_t* rec = plan + L.off_compact + off;
+      int32_t* U = compact ? rec + 2 : dpack + off;
+      // little-endian halves of the 64-bit masks
+      uint32_t* masks = reinterpret_cast<uint32_t*>(compact ? rec + 2 + HCSPMM_COMPACT_K : U + K);
+      if (compact) {
+        rec[0] = (int32_t)w;
+        rec[1] = K4;
       }
+      for (int32_t k = 0; k < (compact ? HCSPMM_COMPACT_K : K); ++k) U[k] = -1;
+      for (int64_t r = r0; r < r1; ++r) {
+        for (int64_t e = rowptr[r]; e < rowptr[r + 1]; ++e) {
+          const int32_t c = e2c[e];
+          if (c < 0 || c >= K) { bad[(size_t)t] = 1; return; }
+          U[c] = col[e];
+          const int lane = 16 * (c & 3) + (int)(r - r0);
+          masks[(c >> 2) * 2 + (lane >> 5)] |= 1u << (lane & 31);
+        }
+      }
+      for (int32_t k = 0; k < K; ++k) uniq_total += U[k] >= 0;
+      dindex[4 * i + 0] = (int32_t)w;
+      dindex[4 * i + 1] = (int32_t)off;
+      dindex[4 * i + 2] = K4;
+      dindex[4 * i + 3] = compact ? 1 : 0;  // 1: offset is relative to the compact section (the kernel does not read this entry)
     }
-    for (int32_t k = 0; k < K; ++k) uniq_total += U[k] >= 0;
-    dindex[4 * i + 0] = (int32_t)w;
-    dindex[4 * i + 1] = compact ? (int32_t)(HCSPMM_COMPACT_WORDS * n_compact_done) : (int32_t)pack_off;
-    dindex[4 * i + 2] = K4;
-    dindex[4 * i + 3] = compact ? 1 : 0;  // 1: offset is relative to the compact section (the kernel does not read this entry)
-    if (compact) ++n_compact_done;
-    else pack_off += K + K4 * 2;
+    uniq_part[(size_t)t] = uniq_total;
+  });
+  int64_t uniq_total = 0;
+  for (int t = 0; t < T; ++t) {
+    if (bad[(size_t)t]) return HCSPMM_EINVAL;
+    uniq_total += uniq_part[(size_t)t];
   }
 
   hcspmm_plan_header h;

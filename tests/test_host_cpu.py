@@ -132,7 +132,23 @@ def _expand_tiny(h, tasks, fix, rp, col):
     return tasks
 
 
-@pytest.mark.parametrize("name,gen", GRAPHS[:4], ids=[g[0] for g in GRAPHS[:4]])
+def _threaded_plan_graph():
+    """Enough windows (>= 4096) for the multi-threaded plan build: planted dense windows, low-degree rows, and
+    hub rows longer than the split threshold."""
+    rp, col = graphs.planted_dense_graph_fast(70000, seed=8, dense_fraction=0.4, k_cols=12, fill=0.5, sparse_degree=3)
+    N = len(rp) - 1
+    rng = np.random.default_rng(8)
+    rows = np.repeat(np.arange(N, dtype=np.int64), np.diff(rp))
+    hubs = np.array([17, 30011, 69990])
+    extra_r = np.repeat(hubs, [700, 1300, 520])
+    extra_c = rng.integers(0, N, extra_r.shape[0])
+    return graphs._to_csr(np.concatenate([rows, extra_r]), np.concatenate([col.astype(np.int64), extra_c]), N)
+
+
+_PLAN_GRAPHS = GRAPHS[:4] + [("threaded_70k", _threaded_plan_graph)]
+
+
+@pytest.mark.parametrize("name,gen", _PLAN_GRAPHS, ids=[g[0] for g in _PLAN_GRAPHS])
 def test_plan_covers_every_entry_exactly_once(name, gen):
     rp, col = gen()
     N, E = len(rp) - 1, len(col)

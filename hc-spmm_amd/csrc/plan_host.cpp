@@ -11,7 +11,7 @@
 //             with -1) and, per 4-column k-step, the 64-bit lane mask of the 16x4 0/1 tile in
 //             v_mfma_f32_16x16x4_f32 A-operand order (lane = 16*(k%4) + row);
 //   compact : dense windows of at most HCSPMM_COMPACT_K columns (the usual case on low-degree graphs) get a
-//             fixed 64-word record instead -- [window, K/4, U[32], 8 x (mask lo, mask hi), pad] -- whose
+//             fixed 64-word record instead -- [window, K/4, U[40], 10 x (mask lo, mask hi), pad] -- whose
 //             address follows from the unit number, so a wave fetches everything it needs to start
 //             gathering with ONE coalesced 256-byte load (dense_index + U + masks are two dependent loads);
 //   fixups  : (row, first partial slot, segment count) for every split row.

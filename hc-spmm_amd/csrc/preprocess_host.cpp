@@ -30,7 +30,7 @@ inline int classify(int32_t size, uint32_t nnz, int32_t num, int rule) {
     // profiles/r01/classifier_refit_v3.json):  z = w1*size + w2*density + b, sparse-row path when z > 0.
     // The boundary depends on the embedding width (at D = 32 the sparse-row path wins below 10-20 % tile
     // density, at D = 128 the dense-tile path wins almost everywhere) and on whether the window gets a compact
-    // record (at most 32 padded columns: two round trips per unit instead of three), so there is one
+    // record (at most 40 padded columns: two round trips per unit instead of three), so there is one
     // coefficient set per (width class, record kind).  Three sets use the density alone: their free fits had a
     // slightly negative w1 (noise inside K <= 130) that extrapolated hub windows onto the dense-tile path.
     // Two sets were then corrected against whole graphs (profiles/r01/classifier_rules_on_workloads.log): the

@@ -391,12 +391,12 @@ __device__ __forceinline__ void dense_unit(const typename E::T* __restrict__ X, 
   if (cok) dense_store<E, VEC>(Z, acc, window, kq, c, N, ldz);
 }
 
-// Compact dense unit: a window of at most 32 (padded) columns whose whole description is one 64-word
+// Compact dense unit: a window of at most HCSPMM_COMPACT_K (40, padded) columns whose whole description is one 64-word
 // record at an address that follows from the unit number (hcspmm.h n_dense_compact): lane l loads word l
 // -- one coalesced 256-byte load -- and the wave can gather: window / K4 / masks go to scalar registers
 // (v_readlane), the column list is broadcast as in dense_unit.  Two round trips per unit instead of three.
 // Same MFMA chain as dense_unit, so the same bits.
-template <typename E, int VEC, int STEPS>
+template <typename E, int VEC, int STEPS, int T0 = 0>
 __device__ __forceinline__ void compact_steps(const typename E::T* __restrict__ X, int word, int K4, int csafe,
                                               bool cok, size_t ldx, int lane, f32x4 (&acc)[VEC]) {
   typedef Lane<E, VEC> Ln;
@@ -405,22 +405,24 @@ __device__ __forceinline__ void compact_steps(const typename E::T* __restrict__ 
   typename Ln::raw_t x[STEPS];
   float a[STEPS];
 #pragma unroll
-  for (int t = 0; t < STEPS; ++t) {
-    idx[t] = __shfl(word, 2 + 4 * t + kq, 64);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane(word, 2 + HCSPMM_COMPACT_K + 2 * t);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane(word, 3 + HCSPMM_COMPACT_K + 2 * t);
+  for (int u = 0; u < STEPS; ++u) {
+    constexpr int kMaskAt = 2 + HCSPMM_COMPACT_K;
+    const int t = T0 + u;
+    idx[u] = __shfl(word, 2 + 4 * t + kq, 64);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane(word, kMaskAt + 2 * t);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane(word, kMaskAt + 1 + 2 * t);
     const unsigned long long m = ((unsigned long long)hi << 32) | lo;
-    a[t] = (t < K4 && ((m >> lane) & 1ull)) ? 1.0f : 0.0f;
-    if (t >= K4) idx[t] = -1;
+    a[u] = (t < K4 && ((m >> lane) & 1ull)) ? 1.0f : 0.0f;
+    if (t >= K4) idx[u] = -1;
   }
 #pragma unroll
-  for (int t = 0; t < STEPS; ++t) x[t] = Ln::load(X + (size_t)max(idx[t], 0) * ldx + csafe);
+  for (int u = 0; u < STEPS; ++u) x[u] = Ln::load(X + (size_t)max(idx[u], 0) * ldx + csafe);
 #pragma unroll
-  for (int t = 0; t < STEPS; ++t) {
-    if (!(cok && idx[t] >= 0)) x[t] = Ln::zero();
-    if (t < K4) {  // wave-uniform
+  for (int u = 0; u < STEPS; ++u) {
+    if (!(cok && idx[u] >= 0)) x[u] = Ln::zero();
+    if (T0 + u < K4) {  // wave-uniform
 #pragma unroll
-      for (int q = 0; q < VEC; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], Ln::elem(x[t], q), acc[q], 0, 0, 0);
+      for (int q = 0; q < VEC; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], Ln::elem(x[u], q), acc[q], 0, 0, 0);
     }
   }
 }
@@ -439,9 +441,14 @@ __device__ __forceinline__ void dense_compact_unit(const typename E::T* __restri
   f32x4 acc[VEC];
 #pragma unroll
   for (int q = 0; q < VEC; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  static_assert(HCSPMM_COMPACT_K % 8 == 0 && HCSPMM_COMPACT_K <= 40 &&
+                    2 + HCSPMM_COMPACT_K + HCSPMM_COMPACT_K / 2 <= HCSPMM_COMPACT_WORDS, "compact record layout");
   if (K4 <= 2) compact_steps<E, VEC, 2>(X, word, K4, csafe, cok, ldx, lane, acc);
   else if (K4 <= 4) compact_steps<E, VEC, 4>(X, word, K4, csafe, cok, ldx, lane, acc);
-  else compact_steps<E, VEC, 8>(X, word, K4, csafe, cok, ldx, lane, acc);
+  else {
+    compact_steps<E, VEC, 8>(X, word, K4, csafe, cok, ldx, lane, acc);
+    if (K4 > 8) compact_steps<E, VEC, 2, 8>(X, word, K4, csafe, cok, ldx, lane, acc);  // K = 40: k-steps 8 and 9
+  }
   if (cok) dense_store<E, VEC>(Z, acc, window, kq, c, N, ldz);
 }
 

@@ -85,7 +85,8 @@ int hcspmm_preprocess_host(const int32_t* row_pointers_h, const int32_t* column_
 #define HCSPMM_PLAN_VERSION 4
 #define HCSPMM_TINY_LEN 2 /* tasks of at most this many entries carry their indices in the descriptor */
 #ifndef HCSPMM_COMPACT_K
-#define HCSPMM_COMPACT_K 32 /* dense windows of at most this many (padded) columns use compact records (0: none) */
+#define HCSPMM_COMPACT_K 40 /* dense windows of at most this many (padded) columns use compact records (0: none);
+                              2 + K + K/2 words must fit HCSPMM_COMPACT_WORDS */
 #endif
 #define HCSPMM_COMPACT_WORDS 64 /* words per compact record */
 #define HCSPMM_PLAN_HEADER_WORDS 32
@@ -117,7 +118,7 @@ typedef struct hcspmm_plan_header {
   int32_t n_tiny;           /* the last n_tiny tasks have at most HCSPMM_TINY_LEN entries and carry their column indices
                                inline: (row, or -(slot+1) for a row segment | index0 | length | index1), absent = -1 */
   int32_t n_dense_compact;  /* the last n_dense_compact dense windows have K <= HCSPMM_COMPACT_K and live in fixed
-                               HCSPMM_COMPACT_WORDS-word records: [window, K/4, U[32], 8 x (mask lo, mask hi), pad] */
+                               HCSPMM_COMPACT_WORDS-word records: [window, K/4, U[40], 10 x (mask lo, mask hi), pad] */
   int32_t off_dense_compact; /* word offset of those records (a multiple of 64) */
   int32_t reserved[4];
 } hcspmm_plan_header;

@@ -69,7 +69,7 @@ int32_t hcspmm_oracle_classify(int32_t size, uint32_t nnz_window, int32_t num, i
   double logit = hcspmm_oracle_logit(size, nnz_window, num);
   if (rule == RULE_MI355X || rule == RULE_MI355X_WIDE) { /* NOT reference rules: the product's own MI355X refits (include/hcspmm.h), same features */
     volatile float dens = (float)nnz_window / (float)(num * BLK_H * BLK_W);
-    int wide = rule == RULE_MI355X_WIDE, compact = num * BLK_W <= 32;
+    int wide = rule == RULE_MI355X_WIDE, compact = num * BLK_W <= 40; /* HCSPMM_COMPACT_K */
     double w1 = 0.0, w2, b;
     if (!wide && compact) { w2 = -30.904771063924702; b = 2.163333974474729; }
     else if (!wide) { w2 = -91.39571130769644; b = 18.406719120321213; }

@@ -190,19 +190,21 @@ def test_plan_covers_every_entry_exactly_once(name, gen):
     # dense windows: U reproduces the sorted unique columns, masks reproduce the 0/1 tiles
     pack = plan[h.off_dense_pack:]
     compact = plan[h.off_dense_compact:]
-    assert h.off_dense_compact % 64 == 0 and h.n_dense_compact == int((dindex[:, 2] <= 8).sum())
-    assert np.all(np.diff(dindex[:, 2]) <= 0)  # widest first, so the compact windows (K <= 32) are the tail
+    CK = 40  # HCSPMM_COMPACT_K
+    assert h.off_dense_compact % 64 == 0 and h.n_dense_compact == int((dindex[:, 2] <= CK // 4).sum())
+    assert np.all(np.diff(dindex[:, 2]) <= 0)  # widest first, so the compact windows (K <= 40) are the tail
     for w, off, K4, is_compact in dindex:
         assert ht[w] == 1
         K = 4 * K4
-        assert K == 8 * bp.numpy()[w] and is_compact == (K <= 32)
+        assert K == 8 * bp.numpy()[w] and is_compact == (K <= CK)
         lo, hi = rp[w * 16], rp[min(w * 16 + 16, N)]
         uniq = np.unique(col[lo:hi])
-        if is_compact:  # fixed 64-word record: window, K/4, U[32], 8 x (mask lo, mask hi), pad
+        if is_compact:  # fixed 64-word record: window, K/4, U[40], 10 x (mask lo, mask hi), pad
             rec = compact[off:off + 64]
-            assert off % 64 == 0 and rec[0] == w and rec[1] == K4 and np.all(rec[2 + K:34] == -1) and np.all(rec[50:] == 0)
-            U, masks = rec[2:2 + K], rec[34:34 + 2 * K4].view(np.uint64)
-            assert np.all(rec[34 + 2 * K4:50] == 0)
+            m0 = 2 + CK
+            assert off % 64 == 0 and rec[0] == w and rec[1] == K4 and np.all(rec[2 + K:m0] == -1)
+            U, masks = rec[2:2 + K], rec[m0:m0 + 2 * K4].view(np.uint64)
+            assert np.all(rec[m0 + 2 * K4:] == 0)
         else:
             U, masks = pack[off:off + K], pack[off + K:off + K + 2 * K4].view(np.uint64)
         assert np.array_equal(U[:len(uniq)], uniq) and np.all(U[len(uniq):] == -1)

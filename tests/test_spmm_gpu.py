@@ -182,10 +182,10 @@ def test_split_rows_are_deterministic_and_within_tolerance(oracle_mod, dev):
 
 @pytest.mark.parametrize("D", [128, 64, 32, 17, 4])
 def test_dense_windows_around_the_compact_record_limit(oracle_mod, dev, D):
-    """Dense windows with exactly K = 1, 2, 8, 9, 16, 25, 31, 32 (compact 64-word records) and 33, 40, 64,
+    """Dense windows with exactly K = 1, 2, 8, 9, 16, 25, 31, 32, 33, 40 (compact 64-word records) and 41, 48, 64,
     130 (regular packs) unique columns in one graph, last window ragged (N % 16 != 0)."""
     rng = np.random.default_rng(5)
-    Ks = [1, 2, 8, 9, 16, 25, 31, 32, 33, 40, 64, 130, 7]
+    Ks = [1, 2, 8, 9, 16, 25, 31, 32, 33, 40, 41, 48, 64, 130, 7]
     N = 16 * len(Ks) - 5
     rows, cols = [], []
     for w, K in enumerate(Ks):
@@ -200,9 +200,29 @@ def test_dense_windows_around_the_compact_record_limit(oracle_mod, dev, D):
     g = Graph(rp, col, dev, force_type=1)
     h = hcspmm.plan_header(g.row_nzr)
     uniq = [len(np.unique(col[rp[16 * w]:rp[min(16 * w + 16, N)]])) for w in range(len(Ks))]
-    assert h.n_dense == len(Ks) and h.n_dense_compact == sum(8 * ((u + 7) // 8) <= 32 for u in uniq)
+    assert h.n_dense == len(Ks) and h.n_dense_compact == sum(8 * ((u + 7) // 8) <= 40 for u in uniq)
     X = rng.standard_normal((N, D)).astype(np.float32)
     _check(oracle_mod, g, X, g.forward(_t(X, dev)), exact_bits=True)
+
+
+@pytest.mark.parametrize("D", [128, 32])
+def test_composite_graph_threaded_plan(oracle_mod, dev, D):
+    """70 K rows: compact dense windows, tiny / ordinary / wide / split sparse rows in one launch, plan built by
+    the multi-threaded host path (>= 4096 windows)."""
+    rp, col = graphs.planted_dense_graph_fast(70000, seed=8, dense_fraction=0.4, k_cols=12, fill=0.5, sparse_degree=3)
+    N = len(rp) - 1
+    rng = np.random.default_rng(8)
+    rows = np.repeat(np.arange(N, dtype=np.int64), np.diff(rp))
+    extra_r = np.repeat(np.array([17, 30011, 69990]), [700, 1300, 520])
+    rp, col = graphs._to_csr(np.concatenate([rows, extra_r]),
+                             np.concatenate([col.astype(np.int64), rng.integers(0, N, extra_r.shape[0])]), N)
+    g = Graph(rp, col, dev)
+    h = hcspmm.plan_header(g.row_nzr)
+    assert h.n_dense_compact > 0 and h.n_tiny > 0 and h.n_split_rows >= 2 and h.n_tasks > h.n_tiny
+    X = rng.standard_normal((N, D)).astype(np.float32)
+    _check(oracle_mod, g, X, g.forward(_t(X, dev)))
+    X16 = torch.from_numpy(X).to(torch.bfloat16).to(dev)
+    _check_h16(oracle_mod, g, X16, g.forward(X16))
 
 
 _H16_GRAPHS = [

@@ -1,4 +1,5 @@
-// spmm_kernels.h -- internal launch interface between capi.hip and spmm_kernels.hip.
+// spmm_kernels.h -- internal launch interface between capi.hip and the kernel translation units
+// (spmm_kernels.hip: fp32, spmm_kernels_h16.hip: fp16 / bf16; device code in spmm_impl.h).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -11,12 +11,84 @@
 #include <algorithm>
 #include <cstdint>
 #include <vector>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include "hcspmm.h"
 
 namespace {
 int loi_reorder_impl(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, int variant, int32_t* perm_out,
                      int32_t* group_sizes_out, int64_t* n_groups_out);
+
+// Position of the first candidate with the largest profit (float)(ones + deg) / (float)(base + deg - shared),
+// strictly greater than every earlier one (and than 0); -1 if none is alive.  LOI.cpp:775-781.
+int64_t scan_best_scalar(const int32_t* deg, const int32_t* shared, const int32_t* alive, int64_t n, int32_t ones,
+                         int32_t base) {
+  int64_t best = -1;
+  float best_profit = 0.0f;
+  for (int64_t i = 0; i < n; ++i) {
+    if (!alive[i]) continue;
+    const float profit = (float)(ones + deg[i]) / (float)(base + deg[i] - shared[i]);
+    if (profit > best_profit) {
+      best = i;
+      best_profit = profit;
+    }
+  }
+  return best;
+}
+
+bool have_avx2() {
+#if defined(__x86_64__)
+  return __builtin_cpu_supports("avx2");
+#else
+  return false;
+#endif
+}
+
+#if defined(__x86_64__)
+// Eight candidates per step: the same int -> float conversions (round to nearest even) and the same IEEE
+// division as the scalar loop; a block is walked lane by lane only when one of its profits beats the running
+// best, so the winner is still the FIRST position holding the maximum.
+__attribute__((target("avx2"))) int64_t scan_best_avx2(const int32_t* deg, const int32_t* shared, const int32_t* alive,
+                                                        int64_t n, int32_t ones, int32_t base) {
+  int64_t best = -1;
+  float best_profit = 0.0f;
+  const __m256i v_ones = _mm256_set1_epi32(ones), v_base = _mm256_set1_epi32(base);
+  int64_t i = 0;
+  for (; i + 8 <= n; i += 8) {
+    const __m256i d = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(deg + i));
+    const __m256i sh = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(shared + i));
+    const __m256 al = _mm256_castsi256_ps(_mm256_loadu_si256(reinterpret_cast<const __m256i*>(alive + i)));
+    const __m256 num = _mm256_cvtepi32_ps(_mm256_add_epi32(v_ones, d));
+    const __m256 den = _mm256_cvtepi32_ps(_mm256_sub_epi32(_mm256_add_epi32(v_base, d), sh));
+    const __m256 profit = _mm256_and_ps(_mm256_div_ps(num, den), al);  // dead lanes price at 0: never > best
+    if (_mm256_movemask_ps(_mm256_cmp_ps(profit, _mm256_set1_ps(best_profit), _CMP_GT_OQ)) != 0) {
+      alignas(32) float p[8];
+      _mm256_store_ps(p, profit);
+      for (int k = 0; k < 8; ++k)
+        if (p[k] > best_profit) {
+          best = i + k;
+          best_profit = p[k];
+        }
+    }
+  }
+  for (; i < n; ++i) {
+    if (!alive[i]) continue;
+    const float profit = (float)(ones + deg[i]) / (float)(base + deg[i] - shared[i]);
+    if (profit > best_profit) {
+      best = i;
+      best_profit = profit;
+    }
+  }
+  return best;
+}
+#else
+int64_t scan_best_avx2(const int32_t* deg, const int32_t* shared, const int32_t* alive, int64_t n, int32_t ones,
+                       int32_t base) {
+  return scan_best_scalar(deg, shared, alive, n, ones, base);
+}
+#endif
 }
 
 extern "C" int hcspmm_loi_reorder(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, int32_t* perm_out,
@@ -41,10 +113,14 @@ int loi_reorder_impl(const int32_t* rowptr, const int32_t* col, int64_t N, int64
   // rows that reference a column: the in-CSR (in-neighbour lists ascending, row-major scan) for
   // reorder_plus_new_direct; reorder_plus_new (LOI.cpp:505-658) walks the column's OWN out-list
   // instead (LOI.cpp:556-557), i.e. it assumes a symmetric graph
+  // The lists are private copies: rows already placed in a group are squeezed out of a list (order kept) the
+  // next time it is walked, so a hub column's list shrinks as the run proceeds instead of being re-read in full
+  // by every group that touches the hub.
   std::vector<int32_t> rowptr_in_v, col_in_v;
   const int32_t* rowptr_in = rowptr;
-  const int32_t* col_in = col;
-  if (variant == HCSPMM_LOI_NEW_DIRECT) {
+  if (variant != HCSPMM_LOI_NEW_DIRECT) {
+    col_in_v.assign(col, col + E);
+  } else {
     rowptr_in_v.assign((size_t)N + 1, 0);
     col_in_v.resize((size_t)E);
     for (int64_t e = 0; e < E; ++e) rowptr_in_v[(size_t)col[e] + 1]++;
@@ -53,16 +129,24 @@ int loi_reorder_impl(const int32_t* rowptr, const int32_t* col, int64_t N, int64
     for (int64_t r = 0; r < N; ++r)
       for (int32_t e = rowptr[r]; e < rowptr[r + 1]; ++e) col_in_v[(size_t)fill[(size_t)col[e]]++] = (int32_t)r;
     rowptr_in = rowptr_in_v.data();
-    col_in = col_in_v.data();
   }
+  int32_t* col_in = col_in_v.data();
+  std::vector<int32_t> in_len((size_t)N);
+  for (int64_t c = 0; c < N; ++c) in_len[(size_t)c] = rowptr_in[c + 1] - rowptr_in[c];
 
+  // Candidates live in position-indexed arrays (discovery order), so that the pricing scan -- 15 passes over
+  // every candidate per group, the bulk of the run time on graphs with hub columns -- reads three dense
+  // arrays front to back instead of chasing visit / shared / row_pointers per vertex, and can be priced eight
+  // at a time (scan_best_avx2: same IEEE conversions and division, same first-seen-wins order).
   std::vector<uint8_t> visit((size_t)N, 0);
-  std::vector<int32_t> shared((size_t)N, 0);      // the reference's `cns`
-  std::vector<int32_t> cand_stamp((size_t)N, -1); // group id in which v became a candidate
+  struct Where { int32_t stamp, pos; };            // group id in which v became a candidate, and its position there
+  std::vector<Where> where((size_t)N, Where{-1, 0});
   std::vector<int32_t> col_stamp((size_t)N, -1);  // group id in which column c joined the group
-  std::vector<int32_t> cand, resi, next_resi;
+  std::vector<int32_t> cand, cand_deg, cand_shared, cand_alive;  // alive: -1 (all bits) or 0, a lane mask
+  std::vector<int32_t> resi, next_resi;
   std::vector<std::vector<int32_t>> groups;
   auto deg = [&](int32_t v) { return rowptr[v + 1] - rowptr[v]; };
+  const bool use_avx2 = have_avx2();
 
   int32_t gid = 0;
   int64_t seed_scan = 0;
@@ -73,6 +157,9 @@ int loi_reorder_impl(const int32_t* rowptr, const int32_t* col, int64_t N, int64
     std::vector<int32_t> grp{seed};
     visit[(size_t)seed] = 1;
     cand.clear();
+    cand_deg.clear();
+    cand_shared.clear();
+    cand_alive.clear();
     int32_t ncols = 0;
     resi.clear();
     for (int32_t e = rowptr[seed]; e < rowptr[seed + 1]; ++e) {
@@ -87,32 +174,38 @@ int loi_reorder_impl(const int32_t* rowptr, const int32_t* col, int64_t N, int64
     bool first = true;
     for (int step = 0; step < 15; ++step) {
       for (int32_t c : resi) {
-        for (int32_t j = rowptr_in[(size_t)c]; j < rowptr_in[(size_t)c + 1]; ++j) {
-          const int32_t r = col_in[(size_t)j];
+        int32_t* lst = col_in + rowptr_in[(size_t)c];
+        const int32_t len = in_len[(size_t)c];
+        int32_t keep = 0;
+        for (int32_t j = 0; j < len; ++j) {
+          const int32_t r = lst[j];
           if (!visit[(size_t)r]) {
-            shared[(size_t)r]++;
-            if (cand_stamp[(size_t)r] != gid) {
-              cand_stamp[(size_t)r] = gid;
+            lst[keep++] = r;
+            Where& wr = where[(size_t)r];
+            if (wr.stamp != gid) {
+              wr.stamp = gid;
+              wr.pos = (int32_t)cand.size();
               cand.push_back(r);
+              cand_deg.push_back(deg(r));
+              cand_shared.push_back(0);
+              cand_alive.push_back(-1);
             }
+            cand_shared[(size_t)wr.pos]++;
           }
         }
+        in_len[(size_t)c] = keep;
       }
-      int32_t best = -1;
-      float best_profit = 0.0f;
-      for (int32_t v : cand) {
-        if (visit[(size_t)v]) continue;
-        const int32_t o = ones + deg(v);
-        // first pick: the reference prices against the seed's own entry count (LOI.cpp:726-727),
-        // later picks against the group's distinct-column count (LOI.cpp:775-776)
-        const int32_t rws = first ? (o - shared[(size_t)v]) : (ncols + deg(v) - shared[(size_t)v]);
-        const float profit = (float)o / (float)rws;
-        if (profit > best_profit) {
-          best = v;
-          best_profit = profit;
-        }
-      }
-      if (best < 0) break;
+      // first pick: the reference prices against the seed's own entry count (LOI.cpp:726-727):
+      //   (ones + deg v) / (ones + deg v - shared v);
+      // later picks against the group's distinct-column count (LOI.cpp:775-776):
+      //   (ones + deg v) / (ncols + deg v - shared v)
+      const int32_t base = first ? ones : ncols;
+      const int64_t n_cand = (int64_t)cand.size();
+      const int64_t bp = use_avx2 ? scan_best_avx2(cand_deg.data(), cand_shared.data(), cand_alive.data(), n_cand, ones, base)
+                                  : scan_best_scalar(cand_deg.data(), cand_shared.data(), cand_alive.data(), n_cand, ones, base);
+      if (bp < 0) break;
+      const int32_t best = cand[(size_t)bp];
+      cand_alive[(size_t)bp] = 0;
       grp.push_back(best);
       visit[(size_t)best] = 1;
       next_resi.clear();
@@ -128,7 +221,6 @@ int loi_reorder_impl(const int32_t* rowptr, const int32_t* col, int64_t N, int64
       ones += deg(best);
       first = false;
     }
-    for (int32_t v : cand) shared[(size_t)v] = 0;
     groups.push_back(std::move(grp));
     ++gid;
   }

@@ -5,6 +5,7 @@ import ctypes
 import glob
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -284,6 +285,33 @@ def test_loi_reorder_matches_reference_golden(path):
     assert np.array_equal(sizes.numpy(), g["group_sizes_new"]) and np.array_equal(perm.numpy(), g["order_new"])
     if "sym" in path:  # symmetric graphs: both variants coincide
         assert np.array_equal(g["order"], g["order_new"])
+
+
+def test_loi_reorder_matches_compiled_reference_on_random_graphs():
+    """Fuzz against the reference's own LOI.cpp, compiled where it lies into oracle/_ref/ (authoring container only:
+    skipped wherever that binary does not exist, e.g. on the GPU box)."""
+    ref_bin = os.path.join(os.path.dirname(GOLD), "..", "oracle", "_ref", "loi_ref")
+    if not os.path.exists(ref_bin):
+        pytest.skip("oracle/_ref/loi_ref not built (no /root/reference here)")
+    sys.path.insert(0, GOLD)
+    try:
+        from make_loi_fixtures import run_ref
+    finally:
+        sys.path.pop(0)
+    rng = np.random.default_rng(77)
+    for i in range(8):
+        N = int(rng.integers(100, 4000))
+        if i % 2 == 0:
+            rp, col = graphs.powerlaw_graph(N, N * int(rng.integers(3, 25)), seed=100 + i,
+                                            max_degree_frac=float(rng.choice([0.02, 0.3])))
+            variants = ("new_direct", "new")
+        else:
+            rp, col = graphs.uniform_graph(N, N * int(rng.integers(1, 10)), seed=100 + i)
+            variants = ("new_direct",)  # the other variant assumes a symmetric graph
+        for variant in variants:
+            sizes, _, order = run_ref(rp, col, variant)
+            perm, gs = hcspmm.loi_reorder(_t(rp), _t(col), variant=variant)
+            assert np.array_equal(perm.numpy(), order) and np.array_equal(gs.numpy(), sizes), (i, variant)
 
 
 def test_loi_reorder_matches_oracle_on_larger_graph():

@@ -1,0 +1,24 @@
+// host_util.h -- shared by the host-side translation units (preprocess_host.cpp, plan_host.cpp).
+#pragma once
+#include <algorithm>
+#include <cstdlib>
+#include <thread>
+
+namespace hcspmm {
+
+// Worker threads for the host passes: HCSPMM_THREADS if set (>= 1), else min(64, hardware threads).
+// Every pass assigns contiguous window ranges to threads and derives output positions from per-range
+// counts, so results do not depend on this number.
+inline int host_threads() {
+  static const int n = [] {
+    if (const char* e = std::getenv("HCSPMM_THREADS")) {
+      const int v = std::atoi(e);
+      if (v >= 1) return std::min(v, 256);
+    }
+    const int hw = (int)std::thread::hardware_concurrency();
+    return std::max(1, std::min(64, hw));
+  }();
+  return n;
+}
+
+}  // namespace hcspmm

@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "hcspmm.h"
+#include "host_util.h"
 
 namespace {
 
@@ -140,8 +141,8 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
 
   // Threads work on contiguous window ranges; every output position follows from per-thread counts in
   // range order, so the blob is identical for any thread count.
-  int T = std::min(64, (int)std::thread::hardware_concurrency());
-  if (T < 1 || W < 4096) T = 1;
+  int T = hcspmm::host_threads();
+  if (W < 4096) T = 1;
   std::vector<int64_t> cut((size_t)T + 1);
   for (int t = 0; t <= T; ++t) cut[(size_t)t] = W * t / T;
   {  // zero the blob (padding, masks) in parallel: it is tens of MB for a multi-million-row graph

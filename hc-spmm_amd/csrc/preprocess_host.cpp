@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "hcspmm.h"
+#include "host_util.h"
 
 namespace {
 
@@ -108,7 +109,7 @@ extern "C" int hcspmm_preprocess_host(const int32_t* rowptr, const int32_t* col,
   for (int64_t r = 0; r < N; ++r)
     if (rowptr[r + 1] < rowptr[r]) return HCSPMM_EINVAL;
 
-  int T = num_threads > 0 ? num_threads : std::min(64, (int)std::thread::hardware_concurrency());
+  int T = num_threads > 0 ? num_threads : hcspmm::host_threads();
   if (T < 1) T = 1;
   if (W < 4 * T || E < (1 << 16)) T = 1;
   if (T == 1) {

@@ -60,7 +60,7 @@ int hcspmm_last_hip_error(void);
  * algorithm (Appendix A of SURVEY.md); empty windows get blockPartition = hybrid_type = 0.
  *   row_pointers_h[N+1], column_index_h[E] : CSR, columns ascending & unique within a row
  *   blockPartition_h[W], hybrid_type_h[W], edgeToColumn_h[E], edgeToRow_h[E] : outputs, W = ceil(N/16)
- *   num_threads <= 0 : use all host cores.
+ *   num_threads <= 0 : HCSPMM_THREADS if set, else min(64, host hardware threads); the outputs do not depend on it.
  *   edgeToRow_h may be NULL (not produced): it is the plain CSR row expansion, which a caller whose
  *   graph lives in HBM can generate there without a host round trip.
  * ---------------------------------------------------------------------------------------- */

@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Randomised parity soak on the GPU: random graphs (sizes, degree laws, hubs, empty rows), embedding widths,
+feature types, classifier rules / forced sub-paths, plan tunables (tiny split thresholds so that segments,
+fix-ups and tiny segments appear everywhere) and the plan-free kernel -- every result checked against the CPU
+oracle with the criteria of tests/test_spmm_gpu.py.  Not part of the test suite (minutes of GPU time):
+
+  python tools/fuzz_parity.py [--cases 300] [--seed 1]
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "hc-spmm_amd"), os.path.join(ROOT, "tests")]
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import hcspmm  # noqa: E402
+import oracle  # noqa: E402
+from hcspmm import graphs  # noqa: E402
+import test_spmm_gpu as T  # noqa: E402  (Graph, _check, _check_h16)
+
+
+def random_graph(rng):
+    kind = rng.integers(0, 6)
+    N = int(rng.choice([1, 2, 15, 16, 17, 100, 1000, 3000, 9000][:]) if rng.random() < 0.3 else rng.integers(1, 6000))
+    if kind == 0:
+        rp, col = graphs.powerlaw_graph(max(N, 8), max(N, 8) * int(rng.integers(1, 30)), seed=int(rng.integers(1 << 30)),
+                                        max_degree_frac=float(rng.choice([0.02, 0.3, 0.9])), symmetric=bool(rng.integers(0, 2)))
+    elif kind == 1:
+        rp, col = graphs.uniform_graph(max(N, 4), max(N, 4) * int(rng.integers(0, 12)) + 1, seed=int(rng.integers(1 << 30)))
+    elif kind == 2:
+        rp, col = graphs.planted_dense_graph_fast(max(N, 32), seed=int(rng.integers(1 << 30)), dense_fraction=float(rng.random()),
+                                                  k_cols=int(rng.choice([4, 12, 20, 33, 40, 41, 64])), fill=float(rng.uniform(0.1, 0.9)),
+                                                  sparse_degree=int(rng.integers(1, 20)))
+    elif kind == 3:
+        rp, col = graphs.molecule_graph(max(N, 50), seed=int(rng.integers(1 << 30)))
+    elif kind == 4:  # explicit degree list: empty rows, rows of 1..3, a few hubs
+        n = max(N, 3)
+        deg = rng.choice([0, 0, 1, 2, 3, 5, 17, 64, 65, 130], size=n)
+        deg = np.minimum(deg, n - 1)
+        if n > 600:
+            deg[rng.integers(0, n, 3)] = rng.integers(n // 3, n - 1, 3)
+        rp = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+        col = np.concatenate([np.sort(rng.choice(n, d, replace=False)) for d in deg if d] or [np.zeros(0, np.int64)]).astype(np.int32)
+    else:
+        n = max(N, 1)
+        rp, col = np.zeros(n + 1, np.int32), np.zeros(0, np.int32)  # no entries at all
+    return rp, col
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=300)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(args.seed)
+    stats = {}
+    for case in range(args.cases):
+        rp, col = random_graph(rng)
+        N = len(rp) - 1
+        D = int(rng.choice([1, 2, 3, 4, 7, 8, 16, 20, 22, 31, 32, 33, 40, 64, 96, 100, 128, 130, 256, 260]))
+        mode = str(rng.choice(["rule0", "rule2", "rule3", "rule4", "all_dense", "all_sparse", "plan_free", "tiny_splits"]))
+        dtype = [torch.float32, torch.float16, torch.bfloat16][int(rng.integers(0, 3))]
+        rule = {"rule2": 2, "rule3": 3, "rule4": 4}.get(mode, 0)
+        g = T.Graph(rp, col, dev, rule=rule, plan=(mode != "plan_free"), force_type={"all_dense": 1, "all_sparse": 0}.get(mode))
+        if mode == "tiny_splits":  # rows longer than 5 entries are cut into segments of 1..5
+            g.row_nzr = hcspmm.build_plan(g.rp_d, g.col_d, g.bp, g.e2c, g.ht, split_threshold=int(rng.integers(2, 6)),
+                                          segment_len=int(rng.integers(1, 6)))
+        X = rng.standard_normal((N, D)).astype(np.float32)
+        tag = "%s/%s" % (mode, str(dtype).replace("torch.", ""))
+        try:
+            if dtype == torch.float32:
+                T._check(oracle, g, X, g.forward(torch.from_numpy(X).to(dev)))
+            else:
+                X16 = torch.from_numpy(X).to(dtype).to(dev)
+                T._check_h16(oracle, g, X16, g.forward(X16))
+        except Exception:
+            print("FAILED case %d: N=%d E=%d D=%d %s" % (case, N, len(col), D, tag))
+            raise
+        stats[tag] = stats.get(tag, 0) + 1
+    torch.cuda.synchronize()
+    print("fuzz ok: %d cases (seed %d)" % (args.cases, args.seed))
+    for k in sorted(stats):
+        print("  %-28s %d" % (k, stats[k]))
+
+
+if __name__ == "__main__":
+    main()

@@ -151,6 +151,8 @@ extern "C" int hcspmm_forward_typed(const void* X, int64_t ldx, void* Z, int64_t
     a.n_dense = ph->n_dense;
     a.off_dense_compact = ph->off_dense_compact;
     a.n_dense_compact = ph->n_dense_compact;
+    a.off_dense_compact2 = ph->off_dense_compact2;
+    a.n_dense_compact2 = ph->n_dense_compact2;
     a.off_fixups = ph->off_fixups;
     a.n_split_rows = ph->n_split_rows;
     wide_choice(ph, D, dtype, &a.n_wide, &a.panel_cols);

@@ -14,13 +14,14 @@
 //             fixed 64-word record instead -- [window, K/4, U[40], 10 x (mask lo, mask hi), pad] -- whose
 //             address follows from the unit number, so a wave fetches everything it needs to start
 //             gathering with ONE coalesced 256-byte load (dense_index + U + masks are two dependent loads);
+//             windows of 48..HCSPMM_COMPACT2_K columns get the same in 128 words (two words per lane);
 //   fixups  : (row, first partial slot, segment count) for every split row.
 // The last n_tiny tasks (those of at most two entries: on low-degree graphs the great majority) carry
 // their column indices INSIDE the descriptor -- (row or -(slot+1), index0, length, index1), absent
 // indices -1 -- so that the kernel needs one memory round trip, not two, before it can gather.
 // Blob layout (int32 words): header[32] | tasks[n_tasks][4] | dense_index[n_dense][4] |
-// dense_pack[...] | compact[n_dense_compact][64] | fixups[n_split_rows][4].  All section offsets are multiples
-// of 4 words, the compact section's of 64.
+// dense_pack[...] | compact2[n_dense_compact2][128] | compact[n_dense_compact][64] | fixups[n_split_rows][4].
+// All section offsets are multiples of 4 words, the compact sections' of 64.
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
@@ -49,11 +50,11 @@ Resolved resolve(const hcspmm_plan_params* p) {
 inline int64_t align4(int64_t x) { return (x + 3) & ~int64_t(3); }
 
 struct Layout {
-  int64_t n_tasks = 0, n_dense = 0, n_compact = 0, n_split_rows = 0, n_partials = 0;
+  int64_t n_tasks = 0, n_dense = 0, n_compact = 0, n_compact2 = 0, n_split_rows = 0, n_partials = 0;
   int64_t dense_pack_words = 0;
   int64_t nnz_sparse = 0, nnz_dense = 0;
   int32_t max_dense_k = 0;
-  int64_t off_tasks = 0, off_dense_index = 0, off_dense_pack = 0, off_compact = 0, off_fixups = 0, total = 0;
+  int64_t off_tasks = 0, off_dense_index = 0, off_dense_pack = 0, off_compact2 = 0, off_compact = 0, off_fixups = 0, total = 0;
 };
 
 int compute_layout(const int32_t* rowptr, int64_t N, const int32_t* bp, const int32_t* ht, const Resolved& rp,
@@ -68,6 +69,7 @@ int compute_layout(const int32_t* rowptr, int64_t N, const int32_t* bp, const in
       L.n_dense++;
       const int64_t K = (int64_t)bp[w] * HCSPMM_BLK_W;
       if (K <= HCSPMM_COMPACT_K) L.n_compact++;
+      else if (K <= HCSPMM_COMPACT2_K) L.n_compact2++;
       else L.dense_pack_words += K + (K / 4) * 2;  // U[K] + one 64-bit mask per 4 columns
       L.nnz_dense += nnz;
       L.max_dense_k = std::max<int32_t>(L.max_dense_k, (int32_t)K);
@@ -89,7 +91,8 @@ int compute_layout(const int32_t* rowptr, int64_t N, const int32_t* bp, const in
   L.off_tasks = HCSPMM_PLAN_HEADER_WORDS;
   L.off_dense_index = align4(L.off_tasks + 4 * L.n_tasks);
   L.off_dense_pack = align4(L.off_dense_index + 4 * L.n_dense);
-  L.off_compact = (L.off_dense_pack + L.dense_pack_words + 63) & ~int64_t(63);
+  L.off_compact2 = (L.off_dense_pack + L.dense_pack_words + 63) & ~int64_t(63);
+  L.off_compact = L.off_compact2 + HCSPMM_COMPACT2_WORDS * L.n_compact2;
   L.off_fixups = align4(L.off_compact + HCSPMM_COMPACT_WORDS * L.n_compact);
   L.total = align4(L.off_fixups + 4 * L.n_split_rows);
   if (L.total > INT32_MAX) return HCSPMM_ERANGE;
@@ -268,7 +271,8 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
   std::stable_sort(dense.begin(), dense.end(), [](const DenseRef& a, const DenseRef& b) { return a.K > b.K; });
   int32_t* dindex = plan + L.off_dense_index;
   int32_t* dpack = plan + L.off_dense_pack;
-  const int64_t n_reg = L.n_dense - L.n_compact;  // sorted by K: the compact windows are the tail of the list
+  // sorted by K: regular windows, then the double-record ones, then the compact ones
+  const int64_t n_reg = L.n_dense - L.n_compact - L.n_compact2, n_c2 = L.n_compact2;
   std::vector<int64_t> pack_at((size_t)n_reg + 1, 0);
   for (int64_t i = 0; i < n_reg; ++i) pack_at[(size_t)i + 1] = pack_at[(size_t)i] + dense[(size_t)i].K + (dense[(size_t)i].K / 4) * 2;
   std::vector<int64_t> uniq_part((size_t)T, 0);
@@ -279,18 +283,20 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
       const int64_t w = dense[(size_t)i].w;
       const int32_t K = dense[(size_t)i].K, K4 = K / 4;
       const int64_t r0 = w * HCSPMM_BLK_H, r1 = std::min<int64_t>(r0 + HCSPMM_BLK_H, N);
-      const bool compact = i >= n_reg;
-      if (compact != (K <= HCSPMM_COMPACT_K)) { bad[(size_t)t] = 1; return; }
-      const int64_t off = compact ? HCSPMM_COMPACT_WORDS * (i - n_reg) : pack_at[(size_t)i];
-      int32_t* rec = plan + L.off_compact + off;
-      int32_t* U = compact ? rec + 2 : dpack + off;
+      const int kind = i < n_reg ? 0 : (i < n_reg + n_c2 ? 2 : 1);  // 0 regular, 2 double record, 1 compact record
+      if (kind != (K <= HCSPMM_COMPACT_K ? 1 : (K <= HCSPMM_COMPACT2_K ? 2 : 0))) { bad[(size_t)t] = 1; return; }
+      const int32_t kmax = kind == 1 ? HCSPMM_COMPACT_K : (kind == 2 ? HCSPMM_COMPACT2_K : K);  // U slots
+      const int64_t off = kind == 1 ? HCSPMM_COMPACT_WORDS * (i - n_reg - n_c2)
+                                    : (kind == 2 ? HCSPMM_COMPACT2_WORDS * (i - n_reg) : pack_at[(size_t)i]);
+      int32_t* rec = plan + (kind == 1 ? L.off_compact : L.off_compact2) + off;
+      int32_t* U = kind ? rec + 2 : dpack + off;
       // little-endian halves of the 64-bit masks
-      uint32_t* masks = reinterpret_cast<uint32_t*>(compact ? rec + 2 + HCSPMM_COMPACT_K : U + K);
-      if (compact) {
+      uint32_t* masks = reinterpret_cast<uint32_t*>(U + kmax);
+      if (kind) {
         rec[0] = (int32_t)w;
         rec[1] = K4;
       }
-      for (int32_t k = 0; k < (compact ? HCSPMM_COMPACT_K : K); ++k) U[k] = -1;
+      for (int32_t k = 0; k < kmax; ++k) U[k] = -1;
       for (int64_t r = r0; r < r1; ++r) {
         for (int64_t e = rowptr[r]; e < rowptr[r + 1]; ++e) {
           const int32_t c = e2c[e];
@@ -304,7 +310,7 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
       dindex[4 * i + 0] = (int32_t)w;
       dindex[4 * i + 1] = (int32_t)off;
       dindex[4 * i + 2] = K4;
-      dindex[4 * i + 3] = compact ? 1 : 0;  // 1: offset is relative to the compact section (the kernel does not read this entry)
+      dindex[4 * i + 3] = kind;  // 1 / 2: offset is relative to that compact section (the kernel does not read the entry)
     }
     uniq_part[(size_t)t] = uniq_total;
   });
@@ -340,6 +346,8 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
   h.n_tiny = (int32_t)n_tiny;
   h.n_dense_compact = (int32_t)L.n_compact;
   h.off_dense_compact = (int32_t)L.off_compact;
+  h.n_dense_compact2 = (int32_t)L.n_compact2;
+  h.off_dense_compact2 = (int32_t)L.off_compact2;
   static_assert(sizeof(hcspmm_plan_header) == HCSPMM_PLAN_HEADER_WORDS * 4, "header size");
   std::memcpy(plan, &h, sizeof(h));
   return HCSPMM_OK;
@@ -353,6 +361,10 @@ extern "C" int hcspmm_plan_check(const hcspmm_plan_header* h, int64_t N, int64_t
   if (h->n_tiny < 0 || h->n_tiny > h->n_tasks) return HCSPMM_EPLAN;
   if (h->n_dense_compact < 0 || h->n_dense_compact > h->n_dense || h->off_dense_compact < h->off_dense_pack ||
       h->off_dense_compact > h->off_fixups || (h->off_dense_compact & 63) != 0)
+    return HCSPMM_EPLAN;
+  if (h->n_dense_compact2 < 0 || h->n_dense_compact2 > h->n_dense - h->n_dense_compact ||
+      h->off_dense_compact2 < h->off_dense_pack || h->off_dense_compact2 > h->off_dense_compact ||
+      (h->off_dense_compact2 & 63) != 0)
     return HCSPMM_EPLAN;
   if (h->off_tasks < HCSPMM_PLAN_HEADER_WORDS || h->off_dense_index < h->off_tasks ||
       h->off_dense_pack < h->off_dense_index || h->off_fixups < h->off_dense_pack ||

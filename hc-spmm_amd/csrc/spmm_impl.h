@@ -391,49 +391,73 @@ __device__ __forceinline__ void dense_unit(const typename E::T* __restrict__ X, 
   if (cok) dense_store<E, VEC>(Z, acc, window, kq, c, N, ldz);
 }
 
-// Compact dense unit: a window of at most HCSPMM_COMPACT_K (40, padded) columns whose whole description is one 64-word
-// record at an address that follows from the unit number (hcspmm.h n_dense_compact): lane l loads word l
-// -- one coalesced 256-byte load -- and the wave can gather: window / K4 / masks go to scalar registers
-// (v_readlane), the column list is broadcast as in dense_unit.  Two round trips per unit instead of three.
-// Same MFMA chain as dense_unit, so the same bits.
-template <typename E, int VEC, int STEPS, int T0 = 0>
-__device__ __forceinline__ void compact_steps(const typename E::T* __restrict__ X, int word, int K4, int csafe,
-                                              bool cok, size_t ldx, int lane, f32x4 (&acc)[VEC]) {
-  typedef Lane<E, VEC> Ln;
-  const int kq = lane >> 4;
-  int idx[STEPS];
-  typename Ln::raw_t x[STEPS];
-  float a[STEPS];
-#pragma unroll
-  for (int u = 0; u < STEPS; ++u) {
-    constexpr int kMaskAt = 2 + HCSPMM_COMPACT_K;
-    const int t = T0 + u;
-    idx[u] = __shfl(word, 2 + 4 * t + kq, 64);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane(word, kMaskAt + 2 * t);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane(word, kMaskAt + 1 + 2 * t);
-    const unsigned long long m = ((unsigned long long)hi << 32) | lo;
-    a[u] = (t < K4 && ((m >> lane) & 1ull)) ? 1.0f : 0.0f;
-    if (t >= K4) idx[u] = -1;
-  }
-#pragma unroll
-  for (int u = 0; u < STEPS; ++u) x[u] = Ln::load(X + (size_t)max(idx[u], 0) * ldx + csafe);
-#pragma unroll
-  for (int u = 0; u < STEPS; ++u) {
-    if (!(cok && idx[u] >= 0)) x[u] = Ln::zero();
-    if (T0 + u < K4) {  // wave-uniform
-#pragma unroll
-      for (int q = 0; q < VEC; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], Ln::elem(x[u], q), acc[q], 0, 0, 0);
+// Compact dense unit: a window whose whole description is one fixed-size record at an address that follows
+// from the unit number (hcspmm.h n_dense_compact / n_dense_compact2): C words per lane -- lane l loads words
+// l, 64 + l, ... with coalesced 256-byte loads -- and the wave can gather: window / K4 / masks go to scalar
+// registers (v_readlane), the column list is broadcast as in dense_unit.  Two round trips per unit instead of
+// three.  C = 1: K <= 40 (64-word record); C = 2: K <= 80 (128 words).  Layout: [window, K/4, U[KMAX],
+// KMAX/4 x (mask lo, mask hi)].  Same MFMA chain as dense_unit, so the same bits.
+template <int C> struct Rec {
+  int w[C];
+  // word `i` of the record (compile-time i): a scalar
+  template <int I> __device__ __forceinline__ int scalar() const { return __builtin_amdgcn_readlane(w[I / 64], I % 64); }
+  // words i0 + kq (kq = 0..3 per lane): a broadcast; the four indices may straddle two of the lane words
+  template <int I0> __device__ __forceinline__ int gather4(int kq) const {
+    if constexpr (I0 / 64 == (I0 + 3) / 64) {
+      return __shfl(w[I0 / 64], (I0 + kq) & 63, 64);
+    } else {
+      const int lo = __shfl(w[I0 / 64], (I0 + kq) & 63, 64);
+      const int hi = __shfl(w[(I0 + 3) / 64], (I0 + kq) & 63, 64);
+      return (I0 + kq) / 64 == I0 / 64 ? lo : hi;
     }
   }
-}
+};
 
-template <typename E, int VEC>
+template <typename E, int VEC, int C, int KMAX, int STEPS, int T0>
+struct CompactSteps {
+  template <int U> static __device__ __forceinline__ void meta(const Rec<C>& rec, int K4, int kq, int lane, int* idx, float* a) {
+    if constexpr (U < STEPS) {
+      constexpr int t = T0 + U;
+      idx[U] = rec.template gather4<2 + 4 * t>(kq);
+      const unsigned lo = (unsigned)rec.template scalar<2 + KMAX + 2 * t>();
+      const unsigned hi = (unsigned)rec.template scalar<3 + KMAX + 2 * t>();
+      const unsigned long long m = ((unsigned long long)hi << 32) | lo;
+      a[U] = (t < K4 && ((m >> lane) & 1ull)) ? 1.0f : 0.0f;
+      if (t >= K4) idx[U] = -1;
+      meta<U + 1>(rec, K4, kq, lane, idx, a);
+    }
+  }
+  static __device__ __forceinline__ void run(const typename E::T* __restrict__ X, const Rec<C>& rec, int K4, int csafe,
+                                             bool cok, size_t ldx, int lane, f32x4 (&acc)[VEC]) {
+    typedef Lane<E, VEC> Ln;
+    int idx[STEPS];
+    typename Ln::raw_t x[STEPS];
+    float a[STEPS];
+    meta<0>(rec, K4, lane >> 4, lane, idx, a);
+#pragma unroll
+    for (int u = 0; u < STEPS; ++u) x[u] = Ln::load(X + (size_t)max(idx[u], 0) * ldx + csafe);
+#pragma unroll
+    for (int u = 0; u < STEPS; ++u) {
+      if (!(cok && idx[u] >= 0)) x[u] = Ln::zero();
+      if (T0 + u < K4) {  // wave-uniform
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], Ln::elem(x[u], q), acc[q], 0, 0, 0);
+      }
+    }
+  }
+};
+
+template <typename E, int VEC, int C>
 __device__ __forceinline__ void dense_compact_unit(const typename E::T* __restrict__ X, typename E::T* __restrict__ Z,
-                                                   const int* __restrict__ rec, int panel, int N, int D, size_t ldx,
+                                                   const int* __restrict__ recp, int panel, int N, int D, size_t ldx,
                                                    size_t ldz, int lane) {
-  const int word = rec[lane];
-  const int window = __builtin_amdgcn_readlane(word, 0);
-  const int K4 = __builtin_amdgcn_readlane(word, 1);
+  constexpr int KMAX = C == 1 ? HCSPMM_COMPACT_K : HCSPMM_COMPACT2_K;
+  static_assert(HCSPMM_COMPACT_K == 40 && HCSPMM_COMPACT2_K == 80 && 2 + KMAX + KMAX / 2 <= 64 * C, "compact record layout");
+  Rec<C> rec;
+#pragma unroll
+  for (int c = 0; c < C; ++c) rec.w[c] = recp[64 * c + lane];
+  const int window = rec.template scalar<0>();
+  const int K4 = rec.template scalar<1>();
   const int kq = lane >> 4, j = lane & 15;
   const int c = panel * 16 * VEC + j * VEC;
   const bool cok = c < D;
@@ -441,13 +465,20 @@ __device__ __forceinline__ void dense_compact_unit(const typename E::T* __restri
   f32x4 acc[VEC];
 #pragma unroll
   for (int q = 0; q < VEC; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-  static_assert(HCSPMM_COMPACT_K % 8 == 0 && HCSPMM_COMPACT_K <= 40 &&
-                    2 + HCSPMM_COMPACT_K + HCSPMM_COMPACT_K / 2 <= HCSPMM_COMPACT_WORDS, "compact record layout");
-  if (K4 <= 2) compact_steps<E, VEC, 2>(X, word, K4, csafe, cok, ldx, lane, acc);
-  else if (K4 <= 4) compact_steps<E, VEC, 4>(X, word, K4, csafe, cok, ldx, lane, acc);
-  else {
-    compact_steps<E, VEC, 8>(X, word, K4, csafe, cok, ldx, lane, acc);
-    if (K4 > 8) compact_steps<E, VEC, 2, 8>(X, word, K4, csafe, cok, ldx, lane, acc);  // K = 40: k-steps 8 and 9
+  if constexpr (C == 1) {  // K4 <= 10
+    if (K4 <= 2) CompactSteps<E, VEC, C, KMAX, 2, 0>::run(X, rec, K4, csafe, cok, ldx, lane, acc);
+    else if (K4 <= 4) CompactSteps<E, VEC, C, KMAX, 4, 0>::run(X, rec, K4, csafe, cok, ldx, lane, acc);
+    else {
+      CompactSteps<E, VEC, C, KMAX, 8, 0>::run(X, rec, K4, csafe, cok, ldx, lane, acc);
+      if (K4 > 8) CompactSteps<E, VEC, C, KMAX, 2, 8>::run(X, rec, K4, csafe, cok, ldx, lane, acc);  // K = 40
+    }
+  } else {  // 12 <= K4 <= 20
+    CompactSteps<E, VEC, C, KMAX, 8, 0>::run(X, rec, K4, csafe, cok, ldx, lane, acc);
+    if (K4 <= 12) CompactSteps<E, VEC, C, KMAX, 4, 8>::run(X, rec, K4, csafe, cok, ldx, lane, acc);
+    else {
+      CompactSteps<E, VEC, C, KMAX, 8, 8>::run(X, rec, K4, csafe, cok, ldx, lane, acc);
+      if (K4 > 16) CompactSteps<E, VEC, C, KMAX, 4, 16>::run(X, rec, K4, csafe, cok, ldx, lane, acc);
+    }
   }
   if (cok) dense_store<E, VEC>(Z, acc, window, kq, c, N, ldz);
 }
@@ -516,15 +547,25 @@ __global__ __launch_bounds__(kThreads, MINW) void hybrid_plan_kernel(PlanArgs a)
     constexpr int VM = DenseV<VEC>::mid;
     int unit = ((int)blockIdx.x - a.sparse_wgs) * kWaves + wave;
     if (unit >= a.n_dense * a.n_panels) return;
-    const int n_reg = a.n_dense - a.n_dense_compact;  // regular windows (K > 32) first, widest first
+    // regular windows (K > 80) first, widest first; then the double-record ones (K <= 80), then the compact ones (K <= 40)
+    const int n_reg = a.n_dense - a.n_dense_compact - a.n_dense_compact2;
     if (unit >= n_reg * a.n_panels) {
       unit -= n_reg * a.n_panels;
+      // elements per lane on the dense-tile path (a panel is 16*dense_vec columns): set by the launcher from D
+      if (unit < a.n_dense_compact2 * a.n_panels) {
+        const int panel = unit / a.n_dense_compact2, ci = unit - panel * a.n_dense_compact2;  // panel-major
+        const int* rec = a.plan + a.off_dense_compact2 + ci * HCSPMM_COMPACT2_WORDS;
+        if (a.dense_vec == VEC) dense_compact_unit<E, VEC, 2>(X, Z, rec, panel, a.N, a.D, a.ldx, a.ldz, lane);
+        else if (a.dense_vec == VM) dense_compact_unit<E, VM, 2>(X, Z, rec, panel, a.N, a.D, a.ldx, a.ldz, lane);
+        else dense_compact_unit<E, 1, 2>(X, Z, rec, panel, a.N, a.D, a.ldx, a.ldz, lane);
+        return;
+      }
+      unit -= a.n_dense_compact2 * a.n_panels;
       const int panel = unit / a.n_dense_compact, ci = unit - panel * a.n_dense_compact;  // panel-major
       const int* rec = a.plan + a.off_dense_compact + ci * HCSPMM_COMPACT_WORDS;
-      // elements per lane on the dense-tile path (a panel is 16*dense_vec columns): set by the launcher from D
-      if (a.dense_vec == VEC) dense_compact_unit<E, VEC>(X, Z, rec, panel, a.N, a.D, a.ldx, a.ldz, lane);
-      else if (a.dense_vec == VM) dense_compact_unit<E, VM>(X, Z, rec, panel, a.N, a.D, a.ldx, a.ldz, lane);
-      else dense_compact_unit<E, 1>(X, Z, rec, panel, a.N, a.D, a.ldx, a.ldz, lane);
+      if (a.dense_vec == VEC) dense_compact_unit<E, VEC, 1>(X, Z, rec, panel, a.N, a.D, a.ldx, a.ldz, lane);
+      else if (a.dense_vec == VM) dense_compact_unit<E, VM, 1>(X, Z, rec, panel, a.N, a.D, a.ldx, a.ldz, lane);
+      else dense_compact_unit<E, 1, 1>(X, Z, rec, panel, a.N, a.D, a.ldx, a.ldz, lane);
       return;
     }
     const int panel = unit / n_reg, di = unit - panel * n_reg;  // panel-major, like the sparse region

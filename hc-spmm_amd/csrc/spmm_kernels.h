@@ -17,7 +17,8 @@ struct PlanArgs {
   size_t ldx, ldz;  // row strides of X and Z in elements (>= D)
   int off_tasks, n_tasks;
   int off_dense_index, off_dense_pack, n_dense;
-  int off_dense_compact, n_dense_compact;  // the last n_dense_compact dense windows use fixed 64-word records
+  int off_dense_compact, n_dense_compact;    // the last n_dense_compact dense windows use fixed 64-word records
+  int off_dense_compact2, n_dense_compact2;  // the n_dense_compact2 before them use 128-word records
   int off_fixups, n_split_rows;
   int N, D;
   int n_wide;                          // the n_wide longest tasks are summed by whole waves

@@ -23,7 +23,8 @@ class Header(ctypes.Structure):
         "n_tasks", "n_dense", "n_split_rows", "n_partials", "off_tasks", "off_dense_index", "off_dense_pack",
         "off_fixups", "nnz_sparse", "nnz_dense", "uniq_dense", "max_dense_k")] + [("n_len_gt", ctypes.c_int32 * 5),
                                                                                   ("n_tiny", ctypes.c_int32), ("n_dense_compact", ctypes.c_int32),
-                                                                                  ("off_dense_compact", ctypes.c_int32), ("reserved", ctypes.c_int32 * 4)]
+                                                                                  ("off_dense_compact", ctypes.c_int32), ("n_dense_compact2", ctypes.c_int32),
+                                                                                  ("off_dense_compact2", ctypes.c_int32), ("reserved", ctypes.c_int32 * 2)]
 
 
 class PlanParams(ctypes.Structure):

@@ -89,6 +89,8 @@ int hcspmm_preprocess_host(const int32_t* row_pointers_h, const int32_t* column_
                               2 + K + K/2 words must fit HCSPMM_COMPACT_WORDS */
 #endif
 #define HCSPMM_COMPACT_WORDS 64 /* words per compact record */
+#define HCSPMM_COMPACT2_K 80    /* wider windows up to this many (padded) columns use double records ... */
+#define HCSPMM_COMPACT2_WORDS 128 /* ... of this many words: [window, K/4, U[80], 20 x (mask lo, mask hi), pad] */
 #define HCSPMM_PLAN_HEADER_WORDS 32
 
 typedef struct hcspmm_plan_header {
@@ -120,7 +122,10 @@ typedef struct hcspmm_plan_header {
   int32_t n_dense_compact;  /* the last n_dense_compact dense windows have K <= HCSPMM_COMPACT_K and live in fixed
                                HCSPMM_COMPACT_WORDS-word records: [window, K/4, U[40], 10 x (mask lo, mask hi), pad] */
   int32_t off_dense_compact; /* word offset of those records (a multiple of 64) */
-  int32_t reserved[4];
+  int32_t n_dense_compact2; /* the n_dense_compact2 dense windows before them have HCSPMM_COMPACT_K < K <= HCSPMM_COMPACT2_K
+                               and live in HCSPMM_COMPACT2_WORDS-word records of the same layout (U[80], 20 masks) */
+  int32_t off_dense_compact2; /* word offset of those records (a multiple of 64) */
+  int32_t reserved[2];
 } hcspmm_plan_header;
 
 /* Tunables for the plan; zero-initialise for defaults. */

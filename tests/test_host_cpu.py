@@ -191,19 +191,23 @@ def test_plan_covers_every_entry_exactly_once(name, gen):
     # dense windows: U reproduces the sorted unique columns, masks reproduce the 0/1 tiles
     pack = plan[h.off_dense_pack:]
     compact = plan[h.off_dense_compact:]
-    CK = 40  # HCSPMM_COMPACT_K
+    CK, CK2 = 40, 80  # HCSPMM_COMPACT_K, HCSPMM_COMPACT2_K
+    compact2 = plan[h.off_dense_compact2:]
     assert h.off_dense_compact % 64 == 0 and h.n_dense_compact == int((dindex[:, 2] <= CK // 4).sum())
-    assert np.all(np.diff(dindex[:, 2]) <= 0)  # widest first, so the compact windows (K <= 40) are the tail
+    assert h.off_dense_compact2 % 64 == 0 and h.off_dense_compact == h.off_dense_compact2 + 128 * h.n_dense_compact2
+    assert h.n_dense_compact2 == int(((dindex[:, 2] > CK // 4) & (dindex[:, 2] <= CK2 // 4)).sum())
+    assert np.all(np.diff(dindex[:, 2]) <= 0)  # widest first: regular, double-record (K <= 80), compact (K <= 40)
     for w, off, K4, is_compact in dindex:
         assert ht[w] == 1
         K = 4 * K4
-        assert K == 8 * bp.numpy()[w] and is_compact == (K <= CK)
+        assert K == 8 * bp.numpy()[w] and is_compact == (1 if K <= CK else (2 if K <= CK2 else 0))
         lo, hi = rp[w * 16], rp[min(w * 16 + 16, N)]
         uniq = np.unique(col[lo:hi])
-        if is_compact:  # fixed 64-word record: window, K/4, U[40], 10 x (mask lo, mask hi), pad
-            rec = compact[off:off + 64]
-            m0 = 2 + CK
-            assert off % 64 == 0 and rec[0] == w and rec[1] == K4 and np.all(rec[2 + K:m0] == -1)
+        if is_compact:  # fixed 64- / 128-word record: window, K/4, U[40 / 80], 10 / 20 x (mask lo, mask hi), pad
+            words, kmax, sec = (64, CK, compact) if is_compact == 1 else (128, CK2, compact2)
+            rec = sec[off:off + words]
+            m0 = 2 + kmax
+            assert off % words == 0 and rec[0] == w and rec[1] == K4 and np.all(rec[2 + K:m0] == -1)
             U, masks = rec[2:2 + K], rec[m0:m0 + 2 * K4].view(np.uint64)
             assert np.all(rec[m0 + 2 * K4:] == 0)
         else:

@@ -182,10 +182,10 @@ def test_split_rows_are_deterministic_and_within_tolerance(oracle_mod, dev):
 
 @pytest.mark.parametrize("D", [128, 64, 32, 17, 4])
 def test_dense_windows_around_the_compact_record_limit(oracle_mod, dev, D):
-    """Dense windows with exactly K = 1, 2, 8, 9, 16, 25, 31, 32, 33, 40 (compact 64-word records) and 41, 48, 64,
+    """Dense windows with exactly K = 1 ... 40 (compact 64-word records), 41 ... 80 (128-word records) and 81, 96,
     130 (regular packs) unique columns in one graph, last window ragged (N % 16 != 0)."""
     rng = np.random.default_rng(5)
-    Ks = [1, 2, 8, 9, 16, 25, 31, 32, 33, 40, 41, 48, 64, 130, 7]
+    Ks = [1, 2, 8, 9, 16, 25, 31, 32, 33, 40, 41, 48, 55, 56, 57, 63, 64, 65, 72, 73, 80, 81, 96, 130, 7]
     N = 16 * len(Ks) - 5
     rows, cols = [], []
     for w, K in enumerate(Ks):
@@ -201,6 +201,7 @@ def test_dense_windows_around_the_compact_record_limit(oracle_mod, dev, D):
     h = hcspmm.plan_header(g.row_nzr)
     uniq = [len(np.unique(col[rp[16 * w]:rp[min(16 * w + 16, N)]])) for w in range(len(Ks))]
     assert h.n_dense == len(Ks) and h.n_dense_compact == sum(8 * ((u + 7) // 8) <= 40 for u in uniq)
+    assert h.n_dense_compact2 == sum(40 < 8 * ((u + 7) // 8) <= 80 for u in uniq)
     X = rng.standard_normal((N, D)).astype(np.float32)
     _check(oracle_mod, g, X, g.forward(_t(X, dev)), exact_bits=True)
 

@@ -579,8 +579,11 @@ __global__ __launch_bounds__(kThreads, MINW) void hybrid_plan_kernel(PlanArgs a)
   }
 }
 
-// Fix-up: rows that were split into segments -- Z[row] = partial[s0] + partial[s0+1] + ... in
-// segment order (deterministic).  One wave per split row.  Partials are fp32 whatever the feature type.
+// Fix-up: rows that were split into segments -- Z[row] = sum of its partial rows, in a fixed order
+// (deterministic): one wave per split row; its 64/L lane groups (L = lanes a row needs) take every (64/L)-th
+// segment with eight loads in flight and are combined by the same xor-shuffle tree as a wide task.  A hub of
+// hundreds of thousands of entries has more than a thousand segments: summed by one lane group, four loads at a
+// time, its wave alone took longer than the rest of the fix-up launch.  Partials are fp32 whatever the feature type.
 template <typename E, int VEC>
 __global__ __launch_bounds__(kThreads) void fixup_kernel(PlanArgs a) {
   typedef Lane<E, VEC> Ln;
@@ -591,19 +594,29 @@ __global__ __launch_bounds__(kThreads) void fixup_kernel(PlanArgs a) {
   if (fi >= a.n_split_rows) return;
   const int4 f = reinterpret_cast<const int4*>(a.plan + a.off_fixups)[fi];
   const int row = f.x, s0 = f.y, ns = f.z;
-  for (int c = lane * VEC; c < a.D; c += 64 * VEC) {
-    const float* p = a.partial + (size_t)s0 * (size_t)a.D + c;
-    acc_t acc = *reinterpret_cast<const acc_t*>(p);
-    int s = 1;
-    for (; s + 4 <= ns; s += 4) {  // four independent loads in flight, added in segment order
-      acc_t v[4];
+  const int slots = (a.D + VEC - 1) / VEC;
+  int L = 1;
+  while (L < slots && L < 64) L <<= 1;  // lanes per row (a.D > 64*VEC: several column passes of 64 lanes)
+  const int R = 64 / L, g = lane / L, sl = lane & (L - 1);
+  for (int c0 = 0; c0 < a.D; c0 += L * VEC) {
+    const int c = c0 + sl * VEC;
+    const bool cok = c < a.D;
+    const float* p = a.partial + (size_t)s0 * (size_t)a.D + (cok ? c : 0);
+    acc_t acc = azero<VEC>();
+    int s = g;
+    for (; s + 7 * R < ns; s += 8 * R) {  // eight independent loads in flight per lane
+      acc_t v[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const acc_t*>(p + (size_t)(s + u) * (size_t)a.D);
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const acc_t*>(p + (size_t)(s + u * R) * (size_t)a.D);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc += v[u];
+      for (int u = 0; u < 8; ++u) acc += v[u];
     }
-    for (; s < ns; ++s) acc += *reinterpret_cast<const acc_t*>(p + (size_t)s * (size_t)a.D);
-    Ln::store(Z + (size_t)row * a.ldz + c, acc);
+    for (; s < ns; s += R) acc += *reinterpret_cast<const acc_t*>(p + (size_t)s * (size_t)a.D);
+    for (int off = L; off < 64; off <<= 1) {
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) aset(acc, q, aget(acc, q) + __shfl_xor(aget(acc, q), off, 64));
+    }
+    if (cok && g == 0) Ln::store(Z + (size_t)row * a.ldz + c, acc);
   }
 }
 

@@ -3,7 +3,7 @@
 // New design (nothing comparable in the reference, which launches one block per window and
 // lets hub rows serialise, hybrid_all_kernel.cu:435-438): the classified windows are turned into
 //   tasks   : one per sparse-path row (rows longer than split_threshold are cut into segments of
-//             segment_len entries whose partial sums a fix-up pass adds in order); tasks are
+//             segment_len entries whose partial sums a fix-up pass adds in a fixed order); tasks are
 //             sorted by descending power-of-two length class (row order inside a class) so that
 //             (a) the 64/L tasks sharing a wave have trip counts within 2x, (b) the hardware
 //             dispatcher sees the heaviest work first, (c) neighbouring tasks touch neighbouring memory;

@@ -40,6 +40,9 @@ def parse_args(argv=None):
     # addition (the reference keeps this idea commented out, HC-SpMM_main.py:143-155): replay the whole
     # training step from a HIP graph -- on small graphs an epoch is launch-bound, not kernel-bound
     p.add_argument("--graph", action="store_true", help="capture the training step into a HIP graph and replay it")
+    # addition: window classifier (hcspmm.h: 0 the reference's intended rule, 2 as shipped, 3 / 4 the MI355X refits
+    # for embedding widths below / from 64)
+    p.add_argument("--rule", type=int, default=0, choices=[0, 1, 2, 3, 4], help="window classifier rule")
     return p.parse_args(argv)
 
 
@@ -78,6 +81,8 @@ def main(argv=None):
     row_pointers = dataset.row_pointers.to(device)
     output = torch.zeros(num_nodes, args.hidden, device=device)
 
+    if args.rule and hasattr(HCSPMM, "set_rule"):
+        HCSPMM.set_rule(args.rule)
     start = time.perf_counter()
     blockPartition, edgeToColumn, edgeToRow, hybrid_type, row_nzr, col_nzr = HCSPMM.preprocess(
         column_index, row_pointers, num_nodes, num_edges, num_row_windows)

@@ -10,7 +10,8 @@
  *
  * Pointer naming: *_h = host memory, *_d = device (HBM) memory.
  * Index arrays are int32 (reference: dataset.py:102-103, K.cu:439-443); features
- * are fp32 row-major.  A is binary: edge values are never read.
+ * are fp32 row-major (hcspmm_forward_typed also takes fp16 / bf16).  A is binary: edge
+ * values are never read.
  */
 #ifndef HCSPMM_H
 #define HCSPMM_H
@@ -82,13 +83,10 @@ int hcspmm_preprocess_host(const int32_t* row_pointers_h, const int32_t* column_
  * read-back).
  * ---------------------------------------------------------------------------------------- */
 #define HCSPMM_PLAN_MAGIC 0x48435350 /* "HCSP" */
-#define HCSPMM_PLAN_VERSION 4
+#define HCSPMM_PLAN_VERSION 5
 #define HCSPMM_TINY_LEN 2 /* tasks of at most this many entries carry their indices in the descriptor */
-#ifndef HCSPMM_COMPACT_K
-#define HCSPMM_COMPACT_K 40 /* dense windows of at most this many (padded) columns use compact records (0: none);
-                              2 + K + K/2 words must fit HCSPMM_COMPACT_WORDS */
-#endif
-#define HCSPMM_COMPACT_WORDS 64 /* words per compact record */
+#define HCSPMM_COMPACT_K 40     /* dense windows of at most this many (padded) columns use compact records ... */
+#define HCSPMM_COMPACT_WORDS 64 /* ... of this many words: [window, K/4, U[40], 10 x (mask lo, mask hi), pad] */
 #define HCSPMM_COMPACT2_K 80    /* wider windows up to this many (padded) columns use double records ... */
 #define HCSPMM_COMPACT2_WORDS 128 /* ... of this many words: [window, K/4, U[80], 20 x (mask lo, mask hi), pad] */
 #define HCSPMM_PLAN_HEADER_WORDS 32

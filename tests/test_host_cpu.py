@@ -40,6 +40,23 @@ def test_library_exports_every_declared_symbol(capi):
     assert ctypes.sizeof(Header) == 4 * Header.WORDS
 
 
+def test_forward_argument_checks_need_no_gpu(capi):
+    """Bad arguments are refused before anything touches the device (so this runs on a CPU-only box)."""
+    L = capi.lib()
+    z = ctypes.c_void_p(0)
+    one = np.zeros(4, np.int32)
+    p = ctypes.c_void_p(one.ctypes.data)
+    common = (z, z, z, z, z, z, z, None)  # graph arrays, plan, header
+    assert L.hcspmm_forward_typed(p, 4, p, 4, 7, *common, 1, 0, 4, z, 0, z) == capi.EINVAL      # unknown dtype
+    assert L.hcspmm_forward_typed(p, 4, p, 4, 0, *common, -1, 0, 4, z, 0, z) == capi.EINVAL     # negative N
+    assert L.hcspmm_forward_typed(p, 2, p, 4, 0, *common, 1, 0, 4, z, 0, z) == capi.EINVAL      # ldx < D
+    assert L.hcspmm_forward_typed(p, 4, p, 4, 2, *common, 0, 0, 4, z, 0, z) == 0                # N == 0: nothing to do
+    assert L.hcspmm_forward_typed(z, 4, p, 4, 1, *common, 1, 0, 4, z, 0, z) == capi.EINVAL      # null X
+    assert L.hcspmm_wide_threshold_typed(None, 128, 9) == 2**31 - 1
+    assert L.hcspmm_wide_threshold_typed(None, 32, 0) == 64 and L.hcspmm_wide_threshold_typed(None, 256, 0) == 2**31 - 1
+    assert L.hcspmm_wide_threshold_typed(None, 256, 2) == 64  # 16-bit rows of 256 columns still fit 32 lanes
+
+
 def test_missing_library_fails_loudly(monkeypatch, capi):
     monkeypatch.setattr(capi, "_LIB", None)
     monkeypatch.setattr(capi, "LIB_PATH", "/nonexistent/libhcspmm.so")

@@ -15,13 +15,16 @@
 //    combine); (b) wide embeddings are processed panel-major, one cache line (128 bytes) per row
 //    at a time across the whole grid; (c) column indices are fetched coalesced once per L
 //    neighbours and broadcast through the LDS crossbar (ds_bpermute); every lane issues 16-byte
-//    loads in branch-free batches of 8.
+//    loads in branch-free batches of 8; (d) rows of at most two entries -- most rows of a low-degree
+//    graph -- are "tiny" tasks whose column indices travel inside the task descriptor.
 //  * dense-tile path: v_mfma_f32_16x16x4_f32 takes its B operand one fp32 per lane, so the
 //    gathered X rows go from HBM straight into MFMA operand registers with 16-byte loads (the
 //    VEC elements of a lane feed VEC MFMAs whose results re-assemble into one vector store);
 //    the 0/1 tile of A arrives as a 64-bit lane mask per k-step, packed by the host in MFMA
 //    lane order.  No LDS round trip, no barrier.  fp32 MFMA is an exact k-ordered fma chain,
 //    so the result equals the sequential sum over the window's ascending unique columns.
+//    Windows of at most 80 columns are described by fixed-size records addressed by unit number
+//    (one or two coalesced loads, then the gathers); wider ones by an index entry + a pack.
 //
 // 16-bit features: rows are gathered as they are stored (half the bytes), widened to fp32 in
 // registers (exact), summed in fp32 in the same order as the fp32 path, and rounded once (RNE) when

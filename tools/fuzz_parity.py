@@ -69,13 +69,25 @@ def main():
             g.row_nzr = hcspmm.build_plan(g.rp_d, g.col_d, g.bp, g.e2c, g.ht, split_threshold=int(rng.integers(2, 6)),
                                           segment_len=int(rng.integers(1, 6)))
         X = rng.standard_normal((N, D)).astype(np.float32)
-        tag = "%s/%s" % (mode, str(dtype).replace("torch.", ""))
+        strided = mode != "plan_free" and rng.random() < 0.3  # X and Z as column slices of wider matrices
+        tag = "%s/%s%s" % (mode, str(dtype).replace("torch.", ""), "/strided" if strided else "")
+
+        def run(Xd):
+            if not strided:
+                return g.forward(Xd)
+            offx, offz = int(rng.choice([0, 1, 4, 8, 32])), int(rng.choice([0, 1, 4, 8, 32]))
+            wide_x = torch.zeros(N, D + offx + int(rng.integers(0, 9)), dtype=Xd.dtype, device=dev)
+            wide_z = torch.full((N, D + offz + int(rng.integers(0, 9))), 7.0, dtype=Xd.dtype, device=dev)
+            wide_x[:, offx:offx + D] = Xd
+            hcspmm.forward_into(wide_x[:, offx:offx + D], wide_z[:, offz:offz + D], *g.args())
+            assert bool((wide_z[:, :offz] == 7).all()) and bool((wide_z[:, offz + D:] == 7).all()), "wrote outside its slice"
+            return wide_z[:, offz:offz + D].contiguous()
         try:
             if dtype == torch.float32:
-                T._check(oracle, g, X, g.forward(torch.from_numpy(X).to(dev)))
+                T._check(oracle, g, X, run(torch.from_numpy(X).to(dev)))
             else:
                 X16 = torch.from_numpy(X).to(dtype).to(dev)
-                T._check_h16(oracle, g, X16, g.forward(X16))
+                T._check_h16(oracle, g, X16, run(X16))
         except Exception:
             print("FAILED case %d: N=%d E=%d D=%d %s" % (case, N, len(col), D, tag))
             raise

@@ -101,13 +101,15 @@ def _i32_host(t):
     return t.to(device="cpu", dtype=torch.int32).contiguous()
 
 
-def preprocess(column_index, row_pointers, num_nodes, num_edges, num_row_windows, rule=None):
+def preprocess(column_index, row_pointers, num_nodes, num_edges, num_row_windows, rule=None, dim=None):
     """HCSPMM.preprocess (hybrid_all.cpp:13-17,501; hybrid_all_kernel.cu:339-408).
 
     Argument order as the reference: column_index FIRST (HC-SpMM_main.py:52).  `num_edges` is
     ignored in favour of column_index.size(0).  Runs on the host (north_star),
     returns [blockPartition, edgeToColumn, edgeToRow, hybrid_type, row_nzr, col_nzr] on the device
     of `column_index`; `row_nzr` carries the MI355X launch plan, `col_nzr` stays the [0] placeholder.
+    `rule` (not in the reference): a HCSPMM_RULE_* number, or "mi355x" together with `dim` = the embedding
+    width the graph will be multiplied at (picks the narrow or the wide MI355X refit).
     """
     L = lib()
     dev = column_index.device
@@ -126,6 +128,10 @@ def preprocess(column_index, row_pointers, num_nodes, num_edges, num_row_windows
     on_gpu = dev.type == "cuda"
     # edgeToRow is the plain CSR row expansion: made on the device when the graph lives there
     e2r = None if on_gpu else torch.empty(E, dtype=torch.int32)
+    if rule == "mi355x":
+        if dim is None:
+            raise RuntimeError('preprocess: rule="mi355x" needs dim= (the embedding width)')
+        rule = mi355x_rule(dim)
     r = _DEFAULT_RULE if rule is None else int(rule)
     check(L.hcspmm_preprocess_host(_ptr(rp_h), _ptr(col_h), N, E, r, 0, _ptr(bp), _ptr(e2c), _ptr(e2r), _ptr(ht)))
     words = ctypes.c_int64(0)

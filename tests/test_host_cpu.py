@@ -40,6 +40,17 @@ def test_library_exports_every_declared_symbol(capi):
     assert ctypes.sizeof(Header) == 4 * Header.WORDS
 
 
+def test_preprocess_rule_by_embedding_width(oracle_mod):
+    rp, col = graphs.planted_dense_graph(640, seed=22)
+    N = len(rp) - 1
+    args = (_t(col), _t(rp), N, len(col), (N + 15) // 16)
+    for dim, rule in ((32, 3), (63, 3), (64, 4), (256, 4)):
+        got = hcspmm.preprocess(*args, rule="mi355x", dim=dim)
+        assert np.array_equal(got[3].numpy(), oracle_mod.preprocess(rp, col, rule)[3])
+    with pytest.raises(RuntimeError, match="needs dim"):
+        hcspmm.preprocess(*args, rule="mi355x")
+
+
 def test_forward_argument_checks_need_no_gpu(capi):
     """Bad arguments are refused before anything touches the device (so this runs on a CPU-only box)."""
     L = capi.lib()

@@ -19,4 +19,4 @@ for D in (32, 128):
         X = torch.randn(N, D, device=dev)
         t = time_us(lambda: hcspmm.forward(X, rp_d, col_d, bp, e2c, e2r, ht1, plan, cn))
         gathered = 65536 * K * D * 4 + N * D * 4
-        print("D=%3d K=%3d  %7.1f us   %5.1f ns/window   %.2f TB/s (unique rows + Z)" % (D, K, t, t * 1e3 / 65536, gathered / t / 1e6))
+        print("D=%3d K=%3d  %7.1f us   %5.2f ns/window   %.2f TB/s (unique rows + Z)" % (D, K, t, t * 1e3 / 65536, gathered / t / 1e6))

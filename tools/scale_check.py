@@ -1,5 +1,6 @@
 """One-off capacity check at BASELINE config 5's FULL size on one GPU: 16 M nodes / 256 M stored
-entries, D = 128 (X and Z 8.2 GB each, N*D = 2.05e9 > 2^31).  Verifies exact integer checksums
+entries, D = 128 (X and Z 8.2 GB each, N*D = 2.05e9 > 2^31); `scale_check.py N E D` for other sizes
+(config 4: 2.45e6 6.2e7 256).  Verifies exact integer checksums
 (X = 1 -> degrees; X[i,:] = i mod 251), prints preprocess and SpMM times."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,7 +10,7 @@ import hcspmm
 
 N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 16_000_000
 E = int(float(sys.argv[2])) if len(sys.argv) > 2 else 256_000_000
-D = 128
+D = int(sys.argv[3]) if len(sys.argv) > 3 else 128
 dev = torch.device("cuda:0")
 t0 = time.perf_counter()
 rng = np.random.default_rng(7)

@@ -44,6 +44,23 @@ def gen_test_tensor(X_prime):
     return torch.arange(n, dtype=torch.float32, device=X_prime.device).unsqueeze(1).expand(n, d).contiguous()
 
 
+def _weight_grad(kept, d):
+    """dW = kept^T d  (reference: torch.mm(X.t(), d), GNN_model.py:79,101,124,160,181,205,230).  The product has a
+    tiny output (dim x hidden) and K = number of nodes; the library GEMM torch.mm picks for that shape on MI355X
+    runs a single output tile over the whole K (400-500 us at 233 K nodes, 40 % of a GCN epoch:
+    profiles/r01/gnn_epoch_kernels.log).  Splitting K into 256 batches of a batched GEMM and summing the partial
+    products is the same arithmetic in a fixed order, 8x faster (profiles/r01/weight_grad_timing.log) and closer to
+    the fp64 product."""
+    n, G = kept.size(0), 256
+    if n < 64 * G or not (kept.is_contiguous() and d.is_contiguous()):
+        return torch.mm(kept.transpose(0, 1), d)
+    m = (n // G) * G
+    out = torch.bmm(kept[:m].view(G, m // G, kept.size(1)).transpose(1, 2), d[:m].view(G, m // G, d.size(1))).sum(0)
+    if m < n:
+        out = out + torch.mm(kept[m:].transpose(0, 1), d[m:])
+    return out
+
+
 def _make_layer_function(name, aggregate_first, fwd_agg, bwd_agg, fwd_fused=None, bwd_fused=None, takes_output=False):
     """Build one autograd Function.  fwd_agg / bwd_agg name the HCSPMM A*X entry points; *_fused,
     when given, name the fused aggregate+update entry point used instead of (A*X then mm)."""
@@ -68,7 +85,7 @@ def _make_layer_function(name, aggregate_first, fwd_agg, bwd_agg, fwd_fused=None
         d_out = d_out.contiguous()
         if aggregate_first:  # kept = A X
             d_agg = torch.mm(d_out, weights.transpose(0, 1))
-            d_w = torch.mm(kept.transpose(0, 1), d_out)
+            d_w = _weight_grad(kept, d_out)
             d_x = getattr(HCSPMM, bwd_agg)(d_agg, *graph)[0]
         else:  # kept = X
             if bwd_fused is not None:
@@ -76,7 +93,7 @@ def _make_layer_function(name, aggregate_first, fwd_agg, bwd_agg, fwd_fused=None
             else:
                 d_agg = getattr(HCSPMM, bwd_agg)(d_out, *graph)[0]
                 d_x = torch.mm(d_agg, weights.transpose(0, 1))
-            d_w = torch.mm(kept.transpose(0, 1), d_agg)
+            d_w = _weight_grad(kept, d_agg)
         return (d_x, d_w) + (None,) * (N_GRAPH + (1 if takes_output else 0))
 
     return type(name, (torch.autograd.Function,), {"forward": staticmethod(forward), "backward": staticmethod(backward),

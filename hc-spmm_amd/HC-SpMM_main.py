@@ -46,6 +46,13 @@ def parse_args(argv=None):
     return p.parse_args(argv)
 
 
+def nll_loss(log_probs, target):
+    """F.nll_loss(log_probs, target) (reference HC-SpMM_main.py:118) as gather + mean: torch's nll_loss reduces
+    233 K rows in one workgroup on this stack (154 + 96 us forward + backward, 9 % of a Reddit-scale epoch:
+    profiles/r01/gnn_epoch_kernels.log); the same number from two parallel kernels."""
+    return -log_probs.gather(1, target.long().unsqueeze(1)).mean()
+
+
 class Net(nn.Module):
     """conv1 (first) -> ReLU -> dropout -> (num_layers - 2) x [hidden conv -> ReLU] -> conv2 (last)
     -> log_softmax   (reference HC-SpMM_main.py:66-110)."""
@@ -100,7 +107,7 @@ def main(argv=None):
     def train():
         model.train()
         optimizer.zero_grad()
-        loss = F.nll_loss(model()[:], dataset.y[:])
+        loss = nll_loss(model()[:], dataset.y[:])
         loss.backward()
         optimizer.step()
         return loss

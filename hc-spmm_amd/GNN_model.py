@@ -52,6 +52,10 @@ def _weight_grad(kept, d):
     products is the same arithmetic in a fixed order, 8x faster (profiles/r01/weight_grad_timing.log) and closer to
     the fp64 product."""
     n, G = kept.size(0), 256
+    if n >= 4096 and hasattr(HCSPMM, "weight_grad"):  # native split-K MFMA kernel (include/hcspmm.h hcspmm_weight_grad)
+        out = HCSPMM.weight_grad(kept, d)
+        if out is not None:
+            return out
     if n < 64 * G or not (kept.is_contiguous() and d.is_contiguous()):
         return torch.mm(kept.transpose(0, 1), d)
     m = (n // G) * G

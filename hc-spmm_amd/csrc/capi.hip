@@ -222,3 +222,19 @@ extern "C" int hcspmm_forward_fused(const float* X, float* out, float* out2, con
                                                    reinterpret_cast<hipStream_t>(stream_v));
   return e == hipSuccess ? HCSPMM_OK : fail_hip(e);
 }
+
+extern "C" size_t hcspmm_weight_grad_workspace(int64_t N, int D, int H) {
+  if (N <= 0 || !hcspmm::weight_grad_supported(D, H)) return 0;
+  return (size_t)hcspmm::weight_grad_groups(N) * (size_t)D * (size_t)H * sizeof(float);
+}
+
+extern "C" int hcspmm_weight_grad(const float* A, int64_t lda, const float* B, int64_t ldb, float* out, int64_t N, int D,
+                                  int H, void* workspace, size_t workspace_bytes, void* stream_v) {
+  if (N <= 0 || D <= 0 || H <= 0 || lda < D || ldb < H || !A || !B || !out) return HCSPMM_EINVAL;
+  if (!hcspmm::weight_grad_supported(D, H)) return HCSPMM_EINVAL;
+  if (N > INT32_MAX) return HCSPMM_ERANGE;
+  if (!workspace || workspace_bytes < hcspmm_weight_grad_workspace(N, D, H)) return HCSPMM_EWORKSPACE;
+  const hipError_t e = hcspmm::launch_weight_grad(A, lda, B, ldb, out, reinterpret_cast<float*>(workspace), N, D, H,
+                                                  reinterpret_cast<hipStream_t>(stream_v));
+  return e == hipSuccess ? HCSPMM_OK : fail_hip(e);
+}

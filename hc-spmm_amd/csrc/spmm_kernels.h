@@ -52,6 +52,13 @@ hipError_t launch_window_f16(const WindowArgs& a, int vec, hipStream_t stream);
 hipError_t launch_plan_bf16(const PlanArgs& a, int vec, hipStream_t stream);
 hipError_t launch_window_bf16(const WindowArgs& a, int vec, hipStream_t stream);
 
+// dW[D x H] = A^T * B (A: N x D rows lda apart, B: N x H rows ldb apart); `partial` holds
+// weight_grad_groups(N) * D * H floats.  Shapes: weight_grad_supported(D, H).
+bool weight_grad_supported(int D, int H);
+int weight_grad_groups(long long N);
+hipError_t launch_weight_grad(const float* A, long long lda, const float* B, long long ldb, float* out, float* partial,
+                              long long N, int D, int H, hipStream_t stream);
+
 // out[N x H] = in[N x D] * W (D x H, element strides ldr / ldc), fp32 MFMA.
 hipError_t launch_dense_update(const float* in, const float* W, long long ldr, long long ldc, float* out, int N,
                                int D, int H, hipStream_t stream);

@@ -141,6 +141,146 @@ static hipError_t launch_stream(const float* in, const float* W, long long ldr, 
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// Weight gradient of the update GEMM:  dW[D x H] = A^T[D x N] * B[N x H]  with K = N rows (hundreds of
+// thousands) and a tiny output.  The reference does it with torch.mm(X.t(), dY) (GNN_model.py:79,101,124,...);
+// the library GEMM picked for that shape on MI355X runs ONE output tile over the whole K (253 us at N = 233 K,
+// 40 % of a GCN epoch, profiles/r01/gnn_epoch_kernels.log).  Here K is split over the grid: each workgroup
+// streams a contiguous block of rows once through fp32 MFMA (lane (i, kq) supplies A[row0 + kq][16*dt + i] as the
+// A operand and B[row0 + kq][16*ht + i] as the B operand of a 16x16x4 step), keeps all D x H / 256 output tiles in
+// registers, folds its four waves through LDS in a fixed order and writes one partial; a second small kernel
+// adds the partials in workgroup order.  Deterministic, bound by reading A and B once.
+// ------------------------------------------------------------------------------------------
+constexpr int kWgUnroll = 4;  // k-steps (of 4 rows) whose loads are in flight together per wave
+
+template <int DT, int HT>
+__global__ __launch_bounds__(kUpdWaves * 64) void weight_grad_partial_kernel(const float* __restrict__ A, long long lda,
+                                                                             const float* __restrict__ B, long long ldb,
+                                                                             float* __restrict__ partial, int N, int D,
+                                                                             int H, int rows_per_wg) {
+  __shared__ float s_red[(kUpdWaves - 1) * DT * HT * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const long long r_begin = (long long)blockIdx.x * rows_per_wg;
+  const long long r_end = min((long long)N, r_begin + rows_per_wg);
+  f32x4 acc[DT][HT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int ht = 0; ht < HT; ++ht) acc[dt][ht] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // wave w takes the k-steps w, w + 4, ... of the block; kWgUnroll of them per iteration
+  for (long long r0 = r_begin + 4 * wave; r0 < r_end; r0 += 16 * kWgUnroll) {
+    float a[kWgUnroll][DT], b[kWgUnroll][HT];
+#pragma unroll
+    for (int u = 0; u < kWgUnroll; ++u) {
+      const long long row = r0 + 16 * u + kq;
+      const bool ok = row < r_end;
+      const float* ar = A + (ok ? row : r_begin) * lda;
+      const float* br = B + (ok ? row : r_begin) * ldb;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) a[u][dt] = (ok && 16 * dt + i < D) ? ar[16 * dt + i] : 0.0f;
+#pragma unroll
+      for (int ht = 0; ht < HT; ++ht) b[u][ht] = (ok && 16 * ht + i < H) ? br[16 * ht + i] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < kWgUnroll; ++u)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int ht = 0; ht < HT; ++ht)
+          acc[dt][ht] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][dt], b[u][ht], acc[dt][ht], 0, 0, 0);
+  }
+  // fold the four waves in wave order (fixed => deterministic)
+  if (wave > 0) {
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_red[(((wave - 1) * DT + dt) * HT + ht) * 256 + r * 64 + lane] = acc[dt][ht][r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float* out = partial + (size_t)blockIdx.x * (size_t)D * (size_t)H;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[dt][ht][r];
+#pragma unroll
+          for (int w = 0; w < kUpdWaves - 1; ++w) v += s_red[((w * DT + dt) * HT + ht) * 256 + r * 64 + lane];
+          const int d = 16 * dt + 4 * kq + r, h = 16 * ht + i;  // accumulator register r of lane (kq, i) is C[4*kq + r][i]
+          if (d < D && h < H) out[d * H + h] = v;
+        }
+  }
+}
+
+// out[e] = sum over the G partials, in workgroup order; 64 elements per workgroup, its four waves take alternate
+// partials (eight loads in flight each) and are folded through LDS in wave order.
+__global__ __launch_bounds__(kUpdWaves * 64) void weight_grad_reduce_kernel(const float* __restrict__ partial,
+                                                                            float* __restrict__ out, int G, int DH) {
+  __shared__ float s_red[kUpdWaves * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int e = (int)blockIdx.x * 64 + lane;
+  float acc = 0.0f;
+  if (e < DH) {
+    int g = wave;
+    for (; g + 7 * kUpdWaves < G; g += 8 * kUpdWaves) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(g + u * kUpdWaves) * (size_t)DH + e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; g < G; g += kUpdWaves) acc += partial[(size_t)g * (size_t)DH + e];
+  }
+  s_red[wave * 64 + lane] = acc;
+  __syncthreads();
+  if (wave == 0 && e < DH) out[e] = ((s_red[lane] + s_red[64 + lane]) + s_red[128 + lane]) + s_red[192 + lane];
+}
+
+int weight_grad_groups(long long N) {  // workgroups of the streaming pass: two per CU, at least 64 rows each
+  long long g = (N + 63) / 64;
+  return (int)(g < 1 ? 1 : (g > 512 ? 512 : g));
+}
+
+bool weight_grad_supported(int D, int H) {
+  const int dt = (D + 15) / 16, ht = (H + 15) / 16;
+  return D > 0 && H > 0 && dt <= 8 && ht <= 4 && dt * ht <= 16;
+}
+
+template <int DT, int HT>
+static hipError_t launch_wg(const float* A, long long lda, const float* B, long long ldb, float* out, float* partial,
+                            long long N, int D, int H, hipStream_t stream) {
+  const int G = weight_grad_groups(N);
+  int rows = (int)((N + G - 1) / G);
+  rows = (rows + 15) / 16 * 16;
+  hipLaunchKernelGGL((weight_grad_partial_kernel<DT, HT>), dim3(G), dim3(kUpdWaves * 64), 0, stream, A, lda, B, ldb,
+                     partial, (int)N, D, H, rows);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(weight_grad_reduce_kernel, dim3((D * H + 63) / 64), dim3(kUpdWaves * 64), 0, stream, partial, out, G,
+                     D * H);
+  return hipGetLastError();
+}
+
+hipError_t launch_weight_grad(const float* A, long long lda, const float* B, long long ldb, float* out, float* partial,
+                              long long N, int D, int H, hipStream_t stream) {
+  const int dt = (D + 15) / 16, ht = (H + 15) / 16;
+#define HCSPMM_WG_CASE(DT_, HT_) \
+  if (dt == DT_ && ht == HT_) return launch_wg<DT_, HT_>(A, lda, B, ldb, out, partial, N, D, H, stream);
+  HCSPMM_WG_CASE(1, 1) HCSPMM_WG_CASE(2, 1) HCSPMM_WG_CASE(3, 1) HCSPMM_WG_CASE(4, 1) HCSPMM_WG_CASE(5, 1) HCSPMM_WG_CASE(6, 1)
+  HCSPMM_WG_CASE(7, 1) HCSPMM_WG_CASE(8, 1)
+  HCSPMM_WG_CASE(1, 2) HCSPMM_WG_CASE(2, 2) HCSPMM_WG_CASE(3, 2) HCSPMM_WG_CASE(4, 2) HCSPMM_WG_CASE(5, 2) HCSPMM_WG_CASE(6, 2)
+  HCSPMM_WG_CASE(7, 2) HCSPMM_WG_CASE(8, 2)
+  HCSPMM_WG_CASE(1, 3) HCSPMM_WG_CASE(2, 3) HCSPMM_WG_CASE(3, 3) HCSPMM_WG_CASE(4, 3) HCSPMM_WG_CASE(5, 3)
+  HCSPMM_WG_CASE(1, 4) HCSPMM_WG_CASE(2, 4) HCSPMM_WG_CASE(3, 4) HCSPMM_WG_CASE(4, 4)
+#undef HCSPMM_WG_CASE
+  return hipErrorInvalidValue;
+}
+
 hipError_t launch_dense_update(const float* in, const float* W, long long ldr, long long ldc, float* out, int N,
                                int D, int H, hipStream_t stream) {
   if (N <= 0 || H <= 0) return hipSuccess;

@@ -22,7 +22,7 @@ __all__ = [
     "forward_fixed64_fused", "forward_final_fused", "forward_final_fused_64", "forward_GIN_final_fused", "backward",
     "backward_fixed32", "backward_fixed32_fused", "backward_final_fused", "backward_fixed64",
     "backward_fixed64_fused", "backward_final_fused_64", "backward_GIN_final_fused", "loi_reorder",
-    "apply_permutation", "plan_header", "forward_rect", "forward_into", "wide_threshold", "build_plan", "set_default_rule", "RULE_INTENDED", "RULE_INTENDED_GUARD",
+    "apply_permutation", "weight_grad", "plan_header", "forward_rect", "forward_into", "wide_threshold", "build_plan", "set_default_rule", "RULE_INTENDED", "RULE_INTENDED_GUARD",
     "RULE_AS_SHIPPED", "RULE_MI355X", "RULE_MI355X_WIDE", "mi355x_rule",
 ]
 
@@ -272,6 +272,26 @@ def forward_into(X, Z, row_pointers, column_index, blockPartition, edgeToColumn,
                                      _ptr(hybrid_type), _ptr(row_nzr) if h is not None else ctypes.c_void_p(0),
                                      ctypes.byref(h) if h is not None else None, N, E, D, _ptr(ws), ws_bytes, stream))
     return Z
+
+
+def weight_grad(A, B):
+    """dW = A^T B for A [N, D], B [N, H] (fp32, unit inner stride): the weight gradient of the update GEMM in the
+    layers' backward passes (reference: torch.mm(X.t(), d_out), GNN_model.py:79,101,...) through the split-K MFMA
+    kernel of hcspmm_weight_grad.  Returns None when the shape is outside the kernel's range (caller: library GEMM)."""
+    L = lib()
+    if not (A.is_cuda and B.is_cuda and A.dtype == B.dtype == torch.float32 and A.dim() == B.dim() == 2
+            and A.size(0) == B.size(0) and A.stride(1) == 1 and B.stride(1) == 1):
+        return None
+    N, D, H = A.size(0), A.size(1), B.size(1)
+    ws_bytes = int(L.hcspmm_weight_grad_workspace(N, D, H))
+    if ws_bytes == 0:
+        return None
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=A.device)
+    out = torch.empty((D, H), dtype=torch.float32, device=A.device)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(A.device).cuda_stream)
+    with torch.cuda.device(A.device):
+        check(L.hcspmm_weight_grad(_ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out), N, D, H, _ptr(ws), ws_bytes, stream))
+    return out
 
 
 # The reference's dim-specialised variants compute the same product (hybrid_all.cpp:223-308);

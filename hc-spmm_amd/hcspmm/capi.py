@@ -53,6 +53,8 @@ SYMBOLS = {
                                       _vp]),
     "hcspmm_forward_fused": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _hp,
                                     _i64, _i64, _int, _vp, _sz, _vp]),
+    "hcspmm_weight_grad_workspace": (_sz, [_i64, _int, _int]),
+    "hcspmm_weight_grad": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _int, _int, _vp, _sz, _vp]),
     "hcspmm_loi_reorder": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, ctypes.POINTER(_i64)]),
     "hcspmm_loi_reorder_variant": (_int, [_vp, _vp, _i64, _i64, _int, _vp, _vp, ctypes.POINTER(_i64)]),
     "hcspmm_apply_permutation": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),

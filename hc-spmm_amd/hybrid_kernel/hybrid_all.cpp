@@ -294,6 +294,24 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
              "apply_permutation");
     return std::vector<torch::Tensor>{rp2, col2};
   }, "relabel a CSR graph with a LOI permutation -> [row_pointers, column_index]");
+  m.def("weight_grad", [](torch::Tensor A, torch::Tensor B) -> torch::Tensor {
+    // dW = A^T B with K = number of nodes (hcspmm.h hcspmm_weight_grad); an undefined tensor (None) when the
+    // shape is outside the kernel's range, so that the caller can use a library GEMM
+    if (!(A.is_cuda() && B.is_cuda() && A.scalar_type() == torch::kFloat && B.scalar_type() == torch::kFloat &&
+          A.dim() == 2 && B.dim() == 2 && A.size(0) == B.size(0) && A.stride(1) == 1 && B.stride(1) == 1))
+      return torch::Tensor();
+    const int64_t N = A.size(0);
+    const int D = (int)A.size(1), H = (int)B.size(1);
+    const size_t need = hcspmm_weight_grad_workspace(N, D, H);
+    if (need == 0) return torch::Tensor();
+    auto ws = torch::empty({(int64_t)(need / 4)}, A.options());
+    auto out = torch::empty({(int64_t)D, (int64_t)H}, A.options());
+    const c10::DeviceGuard guard(A.device());
+    check_rc(hcspmm_weight_grad(A.data_ptr<float>(), A.stride(0), B.data_ptr<float>(), B.stride(0), out.data_ptr<float>(), N,
+                                D, H, ws.data_ptr(), need, (void*)c10::hip::getCurrentHIPStream(A.device().index()).stream()),
+             "weight_grad");
+    return out;
+  }, "dW = A^T B for the layers' backward passes (split-K MFMA kernel); None if the shape is unsupported");
   m.def("plan_info", [](torch::Tensor row_nzr) {
     pybind11::dict d;
     hcspmm_plan_header h;

@@ -230,6 +230,18 @@ int hcspmm_forward_fused(const float* X_d, float* out_d, float* out2_d, const fl
                          int embedding_dim, void* workspace_d, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Weight gradient of the update GEMM, for the autograd glue around the operators:
+ *   dW[D x H] = A^T * B,  A = N x D (rows lda elements apart), B = N x H (rows ldb apart), fp32, dW row-major.
+ * Replaces torch.mm(X.t(), d_out) of the reference's backward passes (GNN_model.py:79,101,124,160,181,205,230):
+ * with K = N in the hundreds of thousands and a tiny output the library GEMM runs one tile over all of K; this
+ * splits K over the grid (fp32 MFMA, partials added in a fixed order: deterministic).
+ * Supported: ceil(D/16) <= 8, ceil(H/16) <= 4, their product <= 16 (else HCSPMM_EINVAL -- use a library GEMM).
+ * ---------------------------------------------------------------------------------------- */
+size_t hcspmm_weight_grad_workspace(int64_t N, int D, int H); /* bytes; 0 if the shape is unsupported */
+int hcspmm_weight_grad(const float* A_d, int64_t lda, const float* B_d, int64_t ldb, float* dW_d, int64_t N, int D,
+                       int H, void* workspace_d, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * LOI layout reorder (host).  Replaces reorder_plus_new_direct LOI.cpp:660-805 with the in-CSR
  * construction and output ordering of its main (LOI.cpp:826-841, :873-891): perm_out_h[N] lists
  * old vertex ids in their new order (full 16-row groups first, then short groups, then vertices

@@ -356,6 +356,33 @@ def test_fused_variants(oracle_mod, dev, D, H):
     assert np.all(np.abs(buf.cpu().numpy().astype(np.float64) - want_out) <= 1e-5 * scale + 1e-30)
 
 
+@pytest.mark.parametrize("N,D,H", [(70001, 96, 32), (5000, 32, 32), (9999, 32, 22), (4097, 64, 64), (300, 7, 3),
+                                   (66000, 128, 32), (1, 16, 16), (20000, 80, 48)])
+def test_weight_grad_kernel(dev, N, D, H):
+    """dW = A^T B (split-K MFMA): against the fp64 product, tolerance 1e-5 * sum_n |a||b| per element (the same kind of
+    bar as A*X); deterministic; strided inputs; unsupported shapes decline."""
+    rng = np.random.default_rng(N + D)
+    A = torch.from_numpy(rng.standard_normal((N, D)).astype(np.float32)).to(dev)
+    B = torch.from_numpy(rng.standard_normal((N, H)).astype(np.float32)).to(dev)
+    got = hcspmm.weight_grad(A, B)
+    assert got is not None and got.shape == (D, H)
+    ref = A.double().t() @ B.double()
+    scale = A.double().abs().t() @ B.double().abs()
+    assert bool(((got.double() - ref).abs() <= 1e-5 * scale + 1e-30).all())
+    assert torch.equal(got, hcspmm.weight_grad(A, B))
+    wideA, wideB = torch.zeros(N, D + 5, device=dev), torch.zeros(N, H + 3, device=dev)
+    wideA[:, 2:2 + D], wideB[:, 1:1 + H] = A, B
+    assert torch.equal(hcspmm.weight_grad(wideA[:, 2:2 + D], wideB[:, 1:1 + H]), got)
+
+
+def test_weight_grad_declines_unsupported(dev):
+    A, B = torch.zeros(100, 200, device=dev), torch.zeros(100, 16, device=dev)
+    assert hcspmm.weight_grad(A, B) is None                      # more than 8 row tiles
+    assert hcspmm.weight_grad(A[:, :96], torch.zeros(100, 80, device=dev)) is None  # more than 4 column tiles
+    assert hcspmm.weight_grad(A[:, :128], torch.zeros(100, 64, device=dev)) is None  # 8 x 4 tiles: too many accumulators
+    assert hcspmm.weight_grad(A[:, :16].double(), B.double()) is None
+
+
 def test_error_behaviour(dev):
     rp, col = graphs.powerlaw_graph(200, 900, seed=1)
     g = Graph(rp, col, dev)

@@ -1,5 +1,7 @@
 import sys, time
-sys.path[:0]=['/root/repo','/root/repo/hc-spmm_amd']
+import os
+ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0]=[ROOT,os.path.join(ROOT,'hc-spmm_amd')]
 import numpy as np, torch
 import hcspmm
 from hcspmm import graphs

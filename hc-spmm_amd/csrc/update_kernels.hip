@@ -7,6 +7,7 @@
 // the reference's backward passes, GNN_model.py:98,120, is consumed without a copy).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "spmm_kernels.h"
 
@@ -242,8 +243,13 @@ __global__ __launch_bounds__(kUpdWaves * 64) void weight_grad_reduce_kernel(cons
 }
 
 int weight_grad_groups(long long N) {  // workgroups of the streaming pass: two per CU, at least 64 rows each
+  static const int cap = [] {
+    const char* e = getenv("HCSPMM_WG_GROUPS");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 512;
+  }();
   long long g = (N + 63) / 64;
-  return (int)(g < 1 ? 1 : (g > 512 ? 512 : g));
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
 bool weight_grad_supported(int D, int H) {

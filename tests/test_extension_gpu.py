@@ -128,3 +128,33 @@ def test_extension_host_utilities(HCSPMM):
     info = HCSPMM.plan_info(outs[4])
     assert info["n_dense"] == int(outs[3].sum()) and info["nnz_sparse"] + info["nnz_dense"] == len(col)
     assert HCSPMM.plan_info(torch.zeros(1, dtype=torch.int32)) == {}
+
+
+@pytest.mark.gpu
+def test_extension_weight_grad_and_layer_backward_use_it(HCSPMM, oracle_mod):
+    """HCSPMM.weight_grad (dW = A^T B, split-K MFMA kernel) and the layers' backward pass on a graph large enough
+    (>= 4096 nodes) for GNN_model._weight_grad to take it: gradients against dense autograd."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    A, B = torch.randn(6000, 96, device=dev), torch.randn(6000, 22, device=dev)
+    got = HCSPMM.weight_grad(A, B)
+    ref = A.double().t() @ B.double()
+    scale = A.double().abs().t() @ B.double().abs()
+    assert got.shape == (96, 22) and bool(((got.double() - ref).abs() <= 1e-5 * scale).all())
+    assert HCSPMM.weight_grad(torch.zeros(10, 200, device=dev), torch.zeros(10, 8, device=dev)) is None
+    import GNN_model
+    rp, col = graphs.powerlaw_graph(5000, 40000, seed=12)
+    N = len(rp) - 1
+    rp_d, col_d = torch.from_numpy(rp).to(dev), torch.from_numpy(col).to(dev)
+    outs = HCSPMM.preprocess(col_d, rp_d, N, len(col), (N + 15) // 16)
+    X = torch.randn(N, 32, device=dev, requires_grad=True)
+    W = torch.randn(32, 16, device=dev, requires_grad=True)
+    Y = GNN_model.HCSPMMFunction.apply(X, W, rp_d, col_d, *outs)
+    G = torch.randn_like(Y)
+    Y.backward(G)
+    Ad = torch.zeros(N, N, dtype=torch.float64, device=dev)
+    Ad[torch.from_numpy(np.repeat(np.arange(N), np.diff(rp))).to(dev), col_d.long()] = 1.0
+    Xd, Wd = X.detach().double().requires_grad_(), W.detach().double().requires_grad_()
+    (Ad @ (Xd @ Wd)).backward(G.double())
+    assert torch.allclose(W.grad.double(), Wd.grad, rtol=1e-4, atol=1e-4 * float(Wd.grad.abs().max()))
+    assert torch.allclose(X.grad.double(), Xd.grad, rtol=1e-4, atol=1e-4 * float(Xd.grad.abs().max()))

@@ -89,16 +89,17 @@ def test_column_remap_round_trip():
     assert np.array_equal(full[g.column_index, 0], X[col[e0:e1], 0])
 
 
-@pytest.mark.parametrize("D", [8, 32])
-def test_sharded_spmm_world2_gloo(tmp_path, D):
+@pytest.mark.parametrize("world,D", [(2, 8), (2, 32), (3, 16)])
+def test_sharded_spmm_gloo(tmp_path, world, D):
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, 7, D, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, 7, D, str(tmp_path)), nprocs=world, join=True)
     covered = []
-    for r in range(2):
+    for r in range(world):
         ok, r0, r1 = np.load(tmp_path / ("ok_%d.npy" % r))
         assert ok == 1
         covered.append((int(r0), int(r1)))
-    assert covered[0][1] == covered[1][0]
+    assert covered[0][0] == 0 and covered[-1][1] == 1003
+    assert all(a[1] == b[0] for a, b in zip(covered[:-1], covered[1:]))
 
 
 def _gpu_worker(rank, world, port, out_dir):

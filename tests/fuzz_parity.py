@@ -2,16 +2,17 @@
 """Randomised parity soak on the GPU: random graphs (sizes, degree laws, hubs, empty rows), embedding widths,
 feature types, classifier rules / forced sub-paths, plan tunables (tiny split thresholds so that segments,
 fix-ups and tiny segments appear everywhere) and the plan-free kernel -- every result checked against the CPU
-oracle with the criteria of tests/test_spmm_gpu.py.  Not part of the test suite (minutes of GPU time):
+oracle with the criteria of tests/test_spmm_gpu.py.  Test infrastructure (it imports the oracle, so it lives under
+tests/), but not collected by pytest -- it costs minutes of GPU time:
 
-  python tools/fuzz_parity.py [--cases 300] [--seed 1]
+  python tests/fuzz_parity.py [--cases 300] [--seed 1]
 """
 import argparse
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "hc-spmm_amd"), os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "hc-spmm_amd"), os.path.join(ROOT, "tests")]  # ROOT = the repository
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 

@@ -215,10 +215,12 @@ def main():
     def local_spmm_into(X_panel_full, Z_view):
         return timed(lambda: hcspmm.forward_into(X_panel_full, Z_view, rp_d, col_d, bp, e2c, e2r, ht, row_nzr, col_nzr))
 
-    # N > 1: gather X in 32-column panels and multiply panel k under the gather of panel k+1
+    # N > 1: gather X in panels of one cache line per row (32 fp32 / 64 16-bit columns) and multiply panel k under
+    # the gather of panel k+1
     n_gather_panels = int(os.environ.get("HCSPMM_GATHER_PANELS", "0"))
+    line_cols = 128 // elem
     if n_gather_panels <= 0:
-        n_gather_panels = D // 32 if (world > 1 and D >= 64 and D % 32 == 0) else 1
+        n_gather_panels = D // line_cols if (world > 1 and D >= 2 * line_cols and D % line_cols == 0) else 1
     op = ShardedSpMM(g, local_spmm, local_spmm_into=local_spmm_into, n_panels=n_gather_panels)
 
     def sync_all():

@@ -187,7 +187,8 @@ def main():
     E = int(len(col))
     rp_d, col_d = torch.from_numpy(rp).to(dev), torch.from_numpy(col).to(dev)
     t0 = time.perf_counter()
-    bp, e2c, e2r, ht, row_nzr, col_nzr = hcspmm.preprocess(col_d, rp_d, n_local, E, (n_local + 15) // 16, rule=args.rule)
+    bp, e2c, e2r, ht, row_nzr, col_nzr = hcspmm.preprocess(col_d, rp_d, n_local, E, (n_local + 15) // 16, rule=args.rule,
+                                                           num_columns=n_local * world * vworld)
     torch.cuda.synchronize()
     prep_ms = (time.perf_counter() - t0) * 1e3
     header = hcspmm.plan_header(row_nzr)

@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include "fingerprint.h"
 #include "hcspmm.h"
 #include "spmm_kernels.h"
 
@@ -45,9 +46,9 @@ inline int nominal_vec(int dtype, int D) {
 extern "C" const char* hcspmm_strerror(int code) {
   switch (code) {
     case HCSPMM_OK: return "ok";
-    case HCSPMM_EINVAL: return "invalid argument";
+    case HCSPMM_EINVAL: return "invalid argument (null / negative size / column id out of range / X too short for the plan)";
     case HCSPMM_ENOMEM: return "host allocation failed";
-    case HCSPMM_EPLAN: return "plan does not match this graph (magic/version/N/E)";
+    case HCSPMM_EPLAN: return "plan does not match this graph (magic/version/N/E/layout/fingerprint)";
     case HCSPMM_EHIP: return "HIP runtime error (see hcspmm_last_hip_error)";
     case HCSPMM_EWORKSPACE: return "workspace too small";
     case HCSPMM_ERANGE: return "size exceeds the int32 index contract";
@@ -115,9 +116,40 @@ extern "C" int32_t hcspmm_wide_threshold(const hcspmm_plan_header* h, int D) {
 }
 
 extern "C" int hcspmm_abi_version(void) { return HCSPMM_ABI_VERSION; }
+
+// Device variant of hcspmm_graph_fingerprint_host: every thread adds the terms of its grid-stride share, a wave
+// folds them with shuffles and issues one 64-bit atomic add (the sum is order-independent, so the result is exact).
+namespace {
+__global__ __launch_bounds__(256) void fingerprint_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                          long long N, long long E, unsigned long long* out) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long acc = (i0 == 0) ? hcspmm::fp_seed(N, E) : 0ull;
+  for (long long r = i0; r <= N; r += stride) acc += hcspmm::fp_term_rowptr((uint64_t)r, rowptr[r]);
+  for (long long e = i0; e < E; e += stride) acc += hcspmm::fp_term_col((uint64_t)e, col[e]);
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+}  // namespace
+
+extern "C" int hcspmm_graph_fingerprint_device(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E,
+                                               uint64_t* out_d, void* stream_v) {
+  if (!rowptr || !out_d || N < 0 || E < 0 || (E > 0 && !col)) return HCSPMM_EINVAL;
+  if (N > INT32_MAX - 16 || E > INT32_MAX) return HCSPMM_ERANGE;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+  hipError_t e = hipMemsetAsync(out_d, 0, sizeof(uint64_t), stream);
+  if (e != hipSuccess) return fail_hip(e);
+  long long blocks = (N + 1 + E + 256 * 16 - 1) / (256 * 16);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(fingerprint_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, rowptr, col, (long long)N, (long long)E,
+                     reinterpret_cast<unsigned long long*>(out_d));
+  e = hipGetLastError();
+  return e == hipSuccess ? HCSPMM_OK : fail_hip(e);
+}
 extern "C" int hcspmm_last_hip_error(void) { return g_last_hip_error; }
 
-extern "C" int hcspmm_forward_typed(const void* X, int64_t ldx, void* Z, int64_t ldz, int dtype, const int32_t* rowptr,
+extern "C" int hcspmm_forward_typed(const void* X, int64_t x_rows, int64_t ldx, void* Z, int64_t ldz, int dtype, const int32_t* rowptr,
                                     const int32_t* col, const int32_t* blockPartition, const int32_t* edgeToColumn,
                                     const int32_t* edgeToRow, const int32_t* hybrid_type, const int32_t* plan_d,
                                     const hcspmm_plan_header* ph, int64_t N, int64_t E, int D, void* workspace,
@@ -130,8 +162,9 @@ extern "C" int hcspmm_forward_typed(const void* X, int64_t ldx, void* Z, int64_t
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
   hipError_t e;
   if (plan_d && ph) {
-    const int rc = hcspmm_plan_check(ph, N, E);
+    const int rc = hcspmm_plan_check(ph, N, E, 0);
     if (rc != HCSPMM_OK) return rc;
+    if (x_rows < ph->num_columns) return HCSPMM_EINVAL;  // the plan gathers rows X does not have
     const size_t need = hcspmm_workspace_bytes(ph, D);
     if (need > 0 && (!workspace || workspace_bytes < need)) return HCSPMM_EWORKSPACE;
     hcspmm::PlanArgs a;
@@ -191,12 +224,12 @@ extern "C" int hcspmm_forward_typed(const void* X, int64_t ldx, void* Z, int64_t
   return e == hipSuccess ? HCSPMM_OK : fail_hip(e);
 }
 
-extern "C" int hcspmm_forward_strided(const float* X, int64_t ldx, float* Z, int64_t ldz, const int32_t* rowptr,
+extern "C" int hcspmm_forward_strided(const float* X, int64_t x_rows, int64_t ldx, float* Z, int64_t ldz, const int32_t* rowptr,
                                       const int32_t* col, const int32_t* blockPartition, const int32_t* edgeToColumn,
                                       const int32_t* edgeToRow, const int32_t* hybrid_type, const int32_t* plan_d,
                                       const hcspmm_plan_header* ph, int64_t N, int64_t E, int D, void* workspace,
                                       size_t workspace_bytes, void* stream_v) {
-  return hcspmm_forward_typed(X, ldx, Z, ldz, HCSPMM_DTYPE_F32, rowptr, col, blockPartition, edgeToColumn, edgeToRow,
+  return hcspmm_forward_typed(X, x_rows, ldx, Z, ldz, HCSPMM_DTYPE_F32, rowptr, col, blockPartition, edgeToColumn, edgeToRow,
                               hybrid_type, plan_d, ph, N, E, D, workspace, workspace_bytes, stream_v);
 }
 
@@ -204,7 +237,7 @@ extern "C" int hcspmm_forward(const float* X, float* Z, const int32_t* rowptr, c
                               const int32_t* blockPartition, const int32_t* edgeToColumn, const int32_t* edgeToRow,
                               const int32_t* hybrid_type, const int32_t* plan_d, const hcspmm_plan_header* ph,
                               int64_t N, int64_t E, int D, void* workspace, size_t workspace_bytes, void* stream_v) {
-  return hcspmm_forward_strided(X, D, Z, D, rowptr, col, blockPartition, edgeToColumn, edgeToRow, hybrid_type, plan_d, ph,
+  return hcspmm_forward_strided(X, N, D, Z, D, rowptr, col, blockPartition, edgeToColumn, edgeToRow, hybrid_type, plan_d, ph,
                                 N, E, D, workspace, workspace_bytes, stream_v);
 }
 

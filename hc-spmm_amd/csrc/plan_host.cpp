@@ -19,8 +19,11 @@
 // The last n_tiny tasks (those of at most two entries: on low-degree graphs the great majority) carry
 // their column indices INSIDE the descriptor -- (row or -(slot+1), index0, length, index1), absent
 // indices -1 -- so that the kernel needs one memory round trip, not two, before it can gather.
-// Blob layout (int32 words): header[32] | tasks[n_tasks][4] | dense_index[n_dense][4] |
-// dense_pack[...] | compact2[n_dense_compact2][128] | compact[n_dense_compact][64] | fixups[n_split_rows][4].
+//   sparse windows : ids of the windows that are NOT dense (ascending) -- the 16-row tiles that the update pass
+//             of the fused operators still has to multiply by the weights (dense windows do it in the launch).
+// Blob layout (int32 words): header[64] | tasks[n_tasks][4] | dense_index[n_dense][4] |
+// dense_pack[...] | compact2[n_dense_compact2][128] | compact[n_dense_compact][64] | fixups[n_split_rows][4] |
+// sparse_windows[n_sparse_windows].
 // All section offsets are multiples of 4 words, the compact sections' of 64.
 #include <algorithm>
 #include <cstdint>
@@ -28,6 +31,7 @@
 #include <thread>
 #include <vector>
 
+#include "fingerprint.h"
 #include "hcspmm.h"
 #include "host_util.h"
 
@@ -54,7 +58,9 @@ struct Layout {
   int64_t dense_pack_words = 0;
   int64_t nnz_sparse = 0, nnz_dense = 0;
   int32_t max_dense_k = 0;
-  int64_t off_tasks = 0, off_dense_index = 0, off_dense_pack = 0, off_compact2 = 0, off_compact = 0, off_fixups = 0, total = 0;
+  int64_t n_sparse_windows = 0;
+  int64_t off_tasks = 0, off_dense_index = 0, off_dense_pack = 0, off_compact2 = 0, off_compact = 0, off_fixups = 0,
+          off_sparse_windows = 0, total = 0;
 };
 
 int compute_layout(const int32_t* rowptr, int64_t N, const int32_t* bp, const int32_t* ht, const Resolved& rp,
@@ -74,6 +80,7 @@ int compute_layout(const int32_t* rowptr, int64_t N, const int32_t* bp, const in
       L.nnz_dense += nnz;
       L.max_dense_k = std::max<int32_t>(L.max_dense_k, (int32_t)K);
     } else {
+      L.n_sparse_windows++;
       for (int64_t r = r0; r < r1; ++r) {
         const int64_t d = (int64_t)rowptr[r + 1] - rowptr[r];
         if (d > rp.split_threshold) {
@@ -94,7 +101,8 @@ int compute_layout(const int32_t* rowptr, int64_t N, const int32_t* bp, const in
   L.off_compact2 = (L.off_dense_pack + L.dense_pack_words + 63) & ~int64_t(63);
   L.off_compact = L.off_compact2 + HCSPMM_COMPACT2_WORDS * L.n_compact2;
   L.off_fixups = align4(L.off_compact + HCSPMM_COMPACT_WORDS * L.n_compact);
-  L.total = align4(L.off_fixups + 4 * L.n_split_rows);
+  L.off_sparse_windows = align4(L.off_fixups + 4 * L.n_split_rows);
+  L.total = align4(L.off_sparse_windows + L.n_sparse_windows);
   if (L.total > INT32_MAX) return HCSPMM_ERANGE;
   *out = L;
   return HCSPMM_OK;
@@ -129,12 +137,54 @@ template <typename F> static void parallel_for(int T, F fn) {
   for (auto& x : th) x.join();
 }
 
-extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, const int32_t* bp,
-                                 const int32_t* e2c, const int32_t* ht, const hcspmm_plan_params* params,
-                                 int32_t* plan, int64_t words) {
+// fingerprint of (rowptr, col) + range check of col against [0, M): one parallel pass over both arrays
+static int fingerprint_and_check(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, int64_t M, uint64_t* out) {
+  if (rowptr[0] != 0 || rowptr[N] != E) return HCSPMM_EINVAL;
+  int T = hcspmm::host_threads();
+  if (N + E < (1 << 18)) T = 1;
+  std::vector<uint64_t> part((size_t)T, 0);
+  std::vector<int> bad((size_t)T, 0);
+  parallel_for(T, [&](int t) {
+    uint64_t acc = 0;
+    uint32_t over = 0;
+    for (int64_t r = (N + 1) * t / T; r < (N + 1) * (t + 1) / T; ++r) acc += hcspmm::fp_term_rowptr((uint64_t)r, rowptr[r]);
+    for (int64_t r = std::max<int64_t>(1, (N + 1) * t / T); r < (N + 1) * (t + 1) / T; ++r) over |= (uint32_t)(rowptr[r] < rowptr[r - 1]);
+    for (int64_t e = E * t / T; e < E * (t + 1) / T; ++e) {
+      acc += hcspmm::fp_term_col((uint64_t)e, col[e]);
+      over |= (uint32_t)((uint32_t)col[e] >= (uint32_t)M);
+    }
+    part[(size_t)t] = acc;
+    bad[(size_t)t] = over != 0;
+  });
+  uint64_t f = hcspmm::fp_seed(N, E);
+  for (int t = 0; t < T; ++t) {
+    if (bad[(size_t)t]) return HCSPMM_EINVAL;
+    f += part[(size_t)t];
+  }
+  *out = f;
+  return HCSPMM_OK;
+}
+
+extern "C" int hcspmm_graph_fingerprint_host(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, uint64_t* out) {
+  if (!rowptr || !out || N < 0 || E < 0 || (E > 0 && !col)) return HCSPMM_EINVAL;
+  if (N > INT32_MAX - 16 || E > INT32_MAX) return HCSPMM_ERANGE;
+  return fingerprint_and_check(rowptr, col, N, E, (int64_t)INT32_MAX + 1, out);  // any non-negative id passes
+}
+
+extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, int64_t M,
+                                 const int32_t* bp, const int32_t* e2c, const int32_t* ht,
+                                 const hcspmm_plan_params* params, int32_t* plan, int64_t words) {
   if (!rowptr || !plan || N < 0 || E < 0) return HCSPMM_EINVAL;
   if (N > 0 && (!bp || !ht)) return HCSPMM_EINVAL;
   if (E > 0 && (!col || !e2c)) return HCSPMM_EINVAL;
+  if (N > INT32_MAX - 16 || E > INT32_MAX) return HCSPMM_ERANGE;
+  if (M <= 0) M = N;
+  if (M > INT32_MAX) return HCSPMM_ERANGE;
+  uint64_t fingerprint = 0;
+  {
+    const int frc = fingerprint_and_check(rowptr, col, N, E, M, &fingerprint);
+    if (frc != HCSPMM_OK) return frc;
+  }
   const Resolved rp = resolve(params);
   Layout L;
   int rc = compute_layout(rowptr, N, bp, ht, rp, &L);
@@ -166,10 +216,10 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
   const int n_cls = length_class(rp.split_threshold) + 1;
   struct Counts {
     std::vector<int64_t> cls;
-    int64_t n_fix = 0, n_slots = 0, n_dense = 0;
+    int64_t n_fix = 0, n_slots = 0, n_dense = 0, n_sparse_w = 0;
   };
   std::vector<Counts> cnt((size_t)T);
-  auto walk = [&](int t, auto&& on_task, auto&& on_fix, auto&& on_dense) {
+  auto walk = [&](int t, auto&& on_task, auto&& on_fix, auto&& on_dense, auto&& on_sparse_window) {
     for (int64_t w = cut[(size_t)t]; w < cut[(size_t)t + 1]; ++w) {
       const int64_t r0 = w * HCSPMM_BLK_H, r1 = std::min<int64_t>(r0 + HCSPMM_BLK_H, N);
       const int64_t nnz = (int64_t)rowptr[r1] - rowptr[r0];
@@ -177,6 +227,7 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
         on_dense(w);
         continue;
       }
+      on_sparse_window(w);
       for (int64_t r = r0; r < r1; ++r) {
         const int32_t e0 = rowptr[r];
         const int64_t d = (int64_t)rowptr[r + 1] - e0;
@@ -198,7 +249,7 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
     c.cls.assign((size_t)n_cls, 0);
     walk(t, [&](int32_t, int32_t, int32_t len, int32_t) { c.cls[(size_t)length_class(len)]++; },
          [&](int64_t, int64_t segs) { c.n_fix++; c.n_slots += segs; return (int64_t)0; },
-         [&](int64_t) { c.n_dense++; });
+         [&](int64_t) { c.n_dense++; }, [&](int64_t) { c.n_sparse_w++; });
   });
   // class starts (bucket 0 = longest class), then per-thread offsets inside each class, in range order
   std::vector<int64_t> start((size_t)n_cls + 1, 0);
@@ -217,7 +268,7 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
   for (int c = 0; c <= length_class(HCSPMM_TINY_LEN) && c < n_cls; ++c)
     for (int t = 0; t < T; ++t) n_tiny += cnt[(size_t)t].cls[(size_t)c];
   std::vector<std::vector<int64_t>> pos((size_t)T, std::vector<int64_t>((size_t)n_cls));
-  std::vector<int64_t> fix_at((size_t)T + 1, 0), slot_at((size_t)T + 1, 0), dense_at((size_t)T + 1, 0);
+  std::vector<int64_t> fix_at((size_t)T + 1, 0), slot_at((size_t)T + 1, 0), dense_at((size_t)T + 1, 0), sparse_w_at((size_t)T + 1, 0);
   {
     std::vector<int64_t> run(start.begin(), start.end() - 1);  // next free slot per bucket
     for (int t = 0; t < T; ++t) {
@@ -228,18 +279,20 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
       fix_at[(size_t)t + 1] = fix_at[(size_t)t] + cnt[(size_t)t].n_fix;
       slot_at[(size_t)t + 1] = slot_at[(size_t)t] + cnt[(size_t)t].n_slots;
       dense_at[(size_t)t + 1] = dense_at[(size_t)t] + cnt[(size_t)t].n_dense;
+      sparse_w_at[(size_t)t + 1] = sparse_w_at[(size_t)t] + cnt[(size_t)t].n_sparse_w;
     }
   }
   if (fix_at[(size_t)T] != L.n_split_rows || slot_at[(size_t)T] != L.n_partials || dense_at[(size_t)T] != L.n_dense ||
-      start.back() != L.n_tasks)
+      start.back() != L.n_tasks || sparse_w_at[(size_t)T] != L.n_sparse_windows)
     return HCSPMM_EINVAL;  // (cannot happen: compute_layout counted the same things)
   struct DenseRef { int32_t w, K; };
   std::vector<DenseRef> dense((size_t)L.n_dense);
   int32_t* out = plan + L.off_tasks;
   int32_t* fix = plan + L.off_fixups;
+  int32_t* sparse_w = plan + L.off_sparse_windows;
   parallel_for(T, [&](int t) {
     std::vector<int64_t>& p = pos[(size_t)t];
-    int64_t n_fix = fix_at[(size_t)t], slot = slot_at[(size_t)t], nd = dense_at[(size_t)t];
+    int64_t n_fix = fix_at[(size_t)t], slot = slot_at[(size_t)t], nd = dense_at[(size_t)t], nsw = sparse_w_at[(size_t)t];
     walk(t,
          [&](int32_t row, int32_t e0, int32_t len, int32_t slot_id) {
            const int64_t q = p[(size_t)length_class(len)]++;
@@ -264,7 +317,8 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
            slot += segs;
            return s0;
          },
-         [&](int64_t w) { dense[(size_t)nd++] = DenseRef{(int32_t)w, bp[w] * HCSPMM_BLK_W}; });
+         [&](int64_t w) { dense[(size_t)nd++] = DenseRef{(int32_t)w, bp[w] * HCSPMM_BLK_W}; },
+         [&](int64_t w) { sparse_w[nsw++] = (int32_t)w; });
   });
 
   // ---- dense windows: widest first (stable, so window order inside a width); pack U and the MFMA lane masks
@@ -348,28 +402,47 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
   h.off_dense_compact = (int32_t)L.off_compact;
   h.n_dense_compact2 = (int32_t)L.n_compact2;
   h.off_dense_compact2 = (int32_t)L.off_compact2;
+  h.num_columns = (int32_t)M;
+  h.n_sparse_windows = (int32_t)L.n_sparse_windows;
+  h.off_sparse_windows = (int32_t)L.off_sparse_windows;
+  h.fingerprint_lo = (uint32_t)(fingerprint & 0xffffffffull);
+  h.fingerprint_hi = (uint32_t)(fingerprint >> 32);
   static_assert(sizeof(hcspmm_plan_header) == HCSPMM_PLAN_HEADER_WORDS * 4, "header size");
   std::memcpy(plan, &h, sizeof(h));
   return HCSPMM_OK;
 }
 
-extern "C" int hcspmm_plan_check(const hcspmm_plan_header* h, int64_t N, int64_t E) {
+extern "C" int hcspmm_plan_check(const hcspmm_plan_header* h, int64_t N, int64_t E, int64_t words_available) {
   if (!h) return HCSPMM_EINVAL;
   if (h->magic != HCSPMM_PLAN_MAGIC || h->version != HCSPMM_PLAN_VERSION) return HCSPMM_EPLAN;
   if (h->num_nodes != N || h->num_edges != E) return HCSPMM_EPLAN;
+  if (h->num_windows != (N + HCSPMM_BLK_H - 1) / HCSPMM_BLK_H || h->num_columns <= 0) return HCSPMM_EPLAN;
   if (h->n_tasks < 0 || h->n_dense < 0 || h->n_split_rows < 0 || h->n_partials < 0) return HCSPMM_EPLAN;
   if (h->n_tiny < 0 || h->n_tiny > h->n_tasks) return HCSPMM_EPLAN;
-  if (h->n_dense_compact < 0 || h->n_dense_compact > h->n_dense || h->off_dense_compact < h->off_dense_pack ||
-      h->off_dense_compact > h->off_fixups || (h->off_dense_compact & 63) != 0)
+  if (h->n_dense_compact < 0 || h->n_dense_compact2 < 0 ||
+      (int64_t)h->n_dense_compact + h->n_dense_compact2 > h->n_dense)
     return HCSPMM_EPLAN;
-  if (h->n_dense_compact2 < 0 || h->n_dense_compact2 > h->n_dense - h->n_dense_compact ||
-      h->off_dense_compact2 < h->off_dense_pack || h->off_dense_compact2 > h->off_dense_compact ||
-      (h->off_dense_compact2 & 63) != 0)
+  if (h->n_sparse_windows < 0 || (int64_t)h->n_sparse_windows + h->n_dense != h->num_windows) return HCSPMM_EPLAN;
+  if (h->n_partials < 2 * (int64_t)h->n_split_rows || h->split_threshold <= 0 || h->segment_len <= 0) return HCSPMM_EPLAN;
+  // the wide-task prefixes index the non-tiny part of the task list, longest first
+  for (int b = 0; b < 5; ++b) {
+    if (h->n_len_gt[b] < 0 || h->n_len_gt[b] > h->n_tasks - h->n_tiny) return HCSPMM_EPLAN;
+    if (b > 0 && h->n_len_gt[b] > h->n_len_gt[b - 1]) return HCSPMM_EPLAN;
+  }
+  // every section starts where the layout says and ends inside the blob, in this order
+  const int64_t n_reg = (int64_t)h->n_dense - h->n_dense_compact - h->n_dense_compact2;
+  if (h->off_tasks != HCSPMM_PLAN_HEADER_WORDS) return HCSPMM_EPLAN;
+  if (h->off_dense_index < h->off_tasks + 4 * (int64_t)h->n_tasks || (h->off_dense_index & 3)) return HCSPMM_EPLAN;
+  if (h->off_dense_pack < h->off_dense_index + 4 * (int64_t)h->n_dense || (h->off_dense_pack & 3)) return HCSPMM_EPLAN;
+  // a regular pack holds at least 88 + 44 words (K > 80)
+  if (h->off_dense_compact2 < h->off_dense_pack + 132 * n_reg || (h->off_dense_compact2 & 63)) return HCSPMM_EPLAN;
+  if (h->off_dense_compact != h->off_dense_compact2 + (int64_t)HCSPMM_COMPACT2_WORDS * h->n_dense_compact2) return HCSPMM_EPLAN;
+  if (h->off_fixups < h->off_dense_compact + (int64_t)HCSPMM_COMPACT_WORDS * h->n_dense_compact || (h->off_fixups & 3))
     return HCSPMM_EPLAN;
-  if (h->off_tasks < HCSPMM_PLAN_HEADER_WORDS || h->off_dense_index < h->off_tasks ||
-      h->off_dense_pack < h->off_dense_index || h->off_fixups < h->off_dense_pack ||
-      h->total_words < h->off_fixups)
-    return HCSPMM_EPLAN;
+  if (h->off_sparse_windows < h->off_fixups + 4 * (int64_t)h->n_split_rows || (h->off_sparse_windows & 3)) return HCSPMM_EPLAN;
+  if (h->total_words < h->off_sparse_windows + (int64_t)h->n_sparse_windows) return HCSPMM_EPLAN;
+  if (words_available > 0 && h->total_words > words_available) return HCSPMM_EPLAN;
+  if ((int64_t)h->nnz_sparse + h->nnz_dense != E) return HCSPMM_EPLAN;
   return HCSPMM_OK;
 }
 

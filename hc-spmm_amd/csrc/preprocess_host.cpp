@@ -55,12 +55,20 @@ inline int classify(int32_t size, uint32_t nnz, int32_t num, int rule) {
   }
 }
 
-void process_windows(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t w_begin, int64_t w_end, int rule,
-                     int32_t* blockPartition, int32_t* edgeToColumn, int32_t* edgeToRow, int32_t* hybrid_type) {
+// *bad is set when a column id lies outside [0, M): the caller turns it into HCSPMM_EINVAL (the pass already
+// touches every entry, so the check is free; on the GPU the same id would be an out-of-bounds gather).
+void process_windows(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t M, int64_t w_begin, int64_t w_end,
+                     int rule, int32_t* blockPartition, int32_t* edgeToColumn, int32_t* edgeToRow, int32_t* hybrid_type,
+                     int* bad) {
   std::vector<int32_t> uniq;
   for (int64_t w = w_begin; w < w_end; ++w) {
     const int64_t r0 = w * HCSPMM_BLK_H, r1 = std::min<int64_t>(r0 + HCSPMM_BLK_H, N);
     const int64_t lo = rowptr[r0], hi = rowptr[r1];
+    {
+      uint32_t over = 0;  // unsigned compare: negative ids are "over" too
+      for (int64_t e = lo; e < hi; ++e) over |= (uint32_t)((uint32_t)col[e] >= (uint32_t)M);
+      if (over) { *bad = 1; return; }
+    }
     if (edgeToRow)  // optional: callers with the graph in HBM expand row ids there instead
       for (int64_t r = r0; r < r1; ++r)
         for (int64_t e = rowptr[r]; e < rowptr[r + 1]; ++e) edgeToRow[e] = (int32_t)r;
@@ -96,10 +104,12 @@ void process_windows(const int32_t* rowptr, const int32_t* col, int64_t N, int64
 
 }  // namespace
 
-extern "C" int hcspmm_preprocess_host(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, int rule,
+extern "C" int hcspmm_preprocess_host(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, int64_t M, int rule,
                                       int num_threads, int32_t* blockPartition, int32_t* edgeToColumn,
                                       int32_t* edgeToRow, int32_t* hybrid_type) {
   if (N < 0 || E < 0 || !rowptr) return HCSPMM_EINVAL;
+  if (M <= 0) M = N;  // the reference's graphs are square
+  if (M > INT32_MAX) return HCSPMM_ERANGE;
   if (E > 0 && (!col || !edgeToColumn)) return HCSPMM_EINVAL;  // edgeToRow may be NULL (skipped)
   if (rule < HCSPMM_RULE_INTENDED || rule > HCSPMM_RULE_MI355X_WIDE) return HCSPMM_EINVAL;
   if (N > INT32_MAX - 16 || E > INT32_MAX) return HCSPMM_ERANGE;
@@ -113,8 +123,9 @@ extern "C" int hcspmm_preprocess_host(const int32_t* rowptr, const int32_t* col,
   if (T < 1) T = 1;
   if (W < 4 * T || E < (1 << 16)) T = 1;
   if (T == 1) {
-    process_windows(rowptr, col, N, 0, W, rule, blockPartition, edgeToColumn, edgeToRow, hybrid_type);
-    return HCSPMM_OK;
+    int bad = 0;
+    process_windows(rowptr, col, N, M, 0, W, rule, blockPartition, edgeToColumn, edgeToRow, hybrid_type, &bad);
+    return bad ? HCSPMM_EINVAL : HCSPMM_OK;
   }
   // contiguous window ranges with ~equal (entries + windows) each
   std::vector<int64_t> cut(T + 1, W);
@@ -127,9 +138,12 @@ extern "C" int hcspmm_preprocess_host(const int32_t* rowptr, const int32_t* col,
     cut[t] = w;
   }
   std::vector<std::thread> th;
+  std::vector<int> bad((size_t)T, 0);
   for (int t = 0; t < T; ++t)
-    th.emplace_back(process_windows, rowptr, col, N, cut[t], cut[t + 1], rule, blockPartition, edgeToColumn, edgeToRow,
-                    hybrid_type);
+    th.emplace_back(process_windows, rowptr, col, N, M, cut[t], cut[t + 1], rule, blockPartition, edgeToColumn, edgeToRow,
+                    hybrid_type, &bad[(size_t)t]);
   for (auto& x : th) x.join();
+  for (int t = 0; t < T; ++t)
+    if (bad[(size_t)t]) return HCSPMM_EINVAL;
   return HCSPMM_OK;
 }

@@ -8,13 +8,15 @@ reference calls it unchanged.  Tensors are plumbing only (device memory + stream
 happens behind the C ABI.  There is NO CPU fallback: if libhcspmm.so is missing, or a feature
 tensor is not on the GPU, the call raises.
 """
+import collections
 import ctypes
 import os
 import threading
+import weakref
 
 import torch
 
-from .capi import (Header, PlanParams, RULE_AS_SHIPPED, RULE_INTENDED, RULE_INTENDED_GUARD, RULE_MI355X,
+from .capi import (EPLAN, Header, PlanParams, RULE_AS_SHIPPED, RULE_INTENDED, RULE_INTENDED_GUARD, RULE_MI355X,
                    RULE_MI355X_WIDE, check, lib)
 
 __all__ = [
@@ -22,7 +24,7 @@ __all__ = [
     "forward_fixed64_fused", "forward_final_fused", "forward_final_fused_64", "forward_GIN_final_fused", "backward",
     "backward_fixed32", "backward_fixed32_fused", "backward_final_fused", "backward_fixed64",
     "backward_fixed64_fused", "backward_final_fused_64", "backward_GIN_final_fused", "loi_reorder",
-    "apply_permutation", "weight_grad", "plan_header", "forward_rect", "forward_into", "wide_threshold", "build_plan", "set_default_rule", "RULE_INTENDED", "RULE_INTENDED_GUARD",
+    "apply_permutation", "weight_grad", "plan_header", "forward_rect", "forward_into", "wide_threshold", "workspace_bytes", "build_plan", "set_default_rule", "RULE_INTENDED", "RULE_INTENDED_GUARD",
     "RULE_AS_SHIPPED", "RULE_MI355X", "RULE_MI355X_WIDE", "mi355x_rule",
 ]
 
@@ -44,37 +46,93 @@ def mi355x_rule(embedding_dim):
 
 
 # ---------------------------------------------------------------------------------------------
-# plan registry: data_ptr of a plan tensor -> (tensor kept alive, host copy of its header).
-# Holding the tensor keeps its address from being reused, so the key stays unambiguous.
+# plan registry: data_ptr of a plan tensor -> host copy of its header.  The registry does NOT keep the
+# tensor alive (a caller that preprocesses many graphs must be able to free their plans): an entry holds a
+# weak reference and is valid only while that tensor lives -- while it does, its memory cannot be handed to
+# another tensor, so the address is an unambiguous key; a dead entry is dropped and the header re-read (one
+# 256-byte device read).  Each entry also remembers which (row_pointers, column_index) tensors the plan has
+# been checked against: preprocess / build_plan register the pair the plan was built from; any other pair is
+# fingerprinted on the device once (hcspmm_graph_fingerprint_device) and refused unless it matches the header.
 # ---------------------------------------------------------------------------------------------
-_REG = {}
+class _Entry:
+    __slots__ = ("ref", "header", "graphs")
+
+    def __init__(self, plan_t, header):
+        self.ref = weakref.ref(plan_t)
+        self.header = header
+        self.graphs = collections.OrderedDict()  # (rowptr ptr, col ptr) -> (weakref, weakref)
+
+
+_REG = collections.OrderedDict()
 _REG_LOCK = threading.Lock()
 _REG_MAX = 256
+_GRAPHS_MAX = 8
 
 
-def _register(plan_t, header):
+def _purge_locked():
+    for k in [k for k, e in _REG.items() if e.ref() is None]:
+        del _REG[k]
+    while len(_REG) >= _REG_MAX:  # least recently used first
+        _REG.popitem(last=False)
+
+
+def _register(plan_t, header, row_pointers=None, column_index=None):
+    e = _Entry(plan_t, header)
+    if row_pointers is not None and column_index is not None and row_pointers.is_cuda:
+        e.graphs[(row_pointers.data_ptr(), column_index.data_ptr())] = (weakref.ref(row_pointers), weakref.ref(column_index))
     with _REG_LOCK:
-        if len(_REG) >= _REG_MAX:
-            _REG.pop(next(iter(_REG)))
-        _REG[plan_t.data_ptr()] = (plan_t, header)
+        _purge_locked()
+        _REG[plan_t.data_ptr()] = e
+    return e
+
+
+def _entry(row_nzr, num_nodes=None, num_edges=None):
+    if row_nzr is None or row_nzr.numel() < Header.WORDS or row_nzr.dtype != torch.int32:
+        return None
+    key = row_nzr.data_ptr()
+    with _REG_LOCK:
+        e = _REG.get(key)
+        if e is not None:
+            if e.ref() is not None:
+                _REG.move_to_end(key)
+                return e
+            del _REG[key]
+    host = row_nzr[:Header.WORDS].cpu().contiguous()
+    h = Header.from_buffer_copy(host.numpy().tobytes())
+    if h.magic != Header.MAGIC:
+        return None
+    if num_nodes is not None and check(lib().hcspmm_plan_check(ctypes.byref(h), num_nodes, num_edges, row_nzr.numel()),
+                                       soft=True) != 0:
+        return None
+    return _register(row_nzr, h)
 
 
 def plan_header(row_nzr, num_nodes=None, num_edges=None):
     """Host copy of the plan header carried by `row_nzr`, or None for the reference's [0]
     placeholder.  A plan tensor first seen here (e.g. a clone) costs one small device read."""
-    if row_nzr is None or row_nzr.numel() < Header.WORDS or row_nzr.dtype != torch.int32:
-        return None
-    hit = _REG.get(row_nzr.data_ptr())
-    if hit is not None:
-        return hit[1]
-    host = row_nzr[:Header.WORDS].cpu().contiguous()
-    h = Header.from_buffer_copy(host.numpy().tobytes())
-    if num_nodes is not None and check(lib().hcspmm_plan_check(ctypes.byref(h), num_nodes, num_edges), soft=True) != 0:
-        return None
-    if h.magic != Header.MAGIC:
-        return None
-    _register(row_nzr, h)
-    return h
+    e = _entry(row_nzr, num_nodes, num_edges)
+    return e.header if e is not None else None
+
+
+def _verify_graph(e, row_pointers, column_index):
+    """The plan of entry `e` was built for ONE graph; N and E alone do not identify it (a LOI reorder keeps both)."""
+    key = (row_pointers.data_ptr(), column_index.data_ptr())
+    hit = e.graphs.get(key)
+    if hit is not None and hit[0]() is not None and hit[1]() is not None:
+        return
+    L = lib()
+    out = torch.empty(1, dtype=torch.int64, device=row_pointers.device)
+    stream = torch.cuda.current_stream(row_pointers.device)
+    with torch.cuda.device(row_pointers.device):
+        check(L.hcspmm_graph_fingerprint_device(_ptr(row_pointers), _ptr(column_index), row_pointers.numel() - 1,
+                                                column_index.numel(), _ptr(out), ctypes.c_void_p(stream.cuda_stream)))
+    got = int(out.item()) & 0xFFFFFFFFFFFFFFFF
+    if got != e.header.fingerprint:
+        raise RuntimeError("hcspmm: plan does not match this graph (row_pointers / column_index differ from the ones "
+                           "the plan was built from) [code %d]" % EPLAN)
+    while len(e.graphs) >= _GRAPHS_MAX:
+        e.graphs.popitem(last=False)
+    e.graphs[key] = (weakref.ref(row_pointers), weakref.ref(column_index))
 
 
 def wide_threshold(row_nzr, embedding_dim, dtype=torch.float32):
@@ -83,6 +141,12 @@ def wide_threshold(row_nzr, embedding_dim, dtype=torch.float32):
     h = plan_header(row_nzr)
     return int(lib().hcspmm_wide_threshold_typed(ctypes.byref(h) if h is not None else None, int(embedding_dim),
                                                  _DTYPES[dtype]))
+
+
+def workspace_bytes(row_nzr, embedding_dim):
+    """Bytes of fp32 workspace a forward with this plan and width needs (partial sums of split rows); 0 without a plan."""
+    h = plan_header(row_nzr)
+    return int(lib().hcspmm_workspace_bytes(ctypes.byref(h), int(embedding_dim))) if h is not None else 0
 
 
 def _ptr(t):
@@ -101,7 +165,7 @@ def _i32_host(t):
     return t.to(device="cpu", dtype=torch.int32).contiguous()
 
 
-def preprocess(column_index, row_pointers, num_nodes, num_edges, num_row_windows, rule=None, dim=None):
+def preprocess(column_index, row_pointers, num_nodes, num_edges, num_row_windows, rule=None, dim=None, num_columns=None):
     """HCSPMM.preprocess (hybrid_all.cpp:13-17,501; hybrid_all_kernel.cu:339-408).
 
     Argument order as the reference: column_index FIRST (HC-SpMM_main.py:52).  `num_edges` is
@@ -110,6 +174,9 @@ def preprocess(column_index, row_pointers, num_nodes, num_edges, num_row_windows
     of `column_index`; `row_nzr` carries the MI355X launch plan, `col_nzr` stays the [0] placeholder.
     `rule` (not in the reference): a HCSPMM_RULE_* number, or "mi355x" together with `dim` = the embedding
     width the graph will be multiplied at (picks the narrow or the wide MI355X refit).
+    `num_columns` (not in the reference, whose graphs are square): rows of the matrix the column ids index, for
+    a row block of a sharded graph.  Column ids outside [0, num_columns) raise -- on the GPU they would be
+    out-of-bounds gathers.
     """
     L = lib()
     dev = column_index.device
@@ -133,11 +200,12 @@ def preprocess(column_index, row_pointers, num_nodes, num_edges, num_row_windows
             raise RuntimeError('preprocess: rule="mi355x" needs dim= (the embedding width)')
         rule = mi355x_rule(dim)
     r = _DEFAULT_RULE if rule is None else int(rule)
-    check(L.hcspmm_preprocess_host(_ptr(rp_h), _ptr(col_h), N, E, r, 0, _ptr(bp), _ptr(e2c), _ptr(e2r), _ptr(ht)))
+    M = N if num_columns is None else int(num_columns)
+    check(L.hcspmm_preprocess_host(_ptr(rp_h), _ptr(col_h), N, E, M, r, 0, _ptr(bp), _ptr(e2c), _ptr(e2r), _ptr(ht)))
     words = ctypes.c_int64(0)
     check(L.hcspmm_plan_words(_ptr(rp_h), N, E, _ptr(bp), _ptr(ht), ctypes.byref(_PLAN_PARAMS), ctypes.byref(words)))
     plan = torch.empty(max(int(words.value), Header.WORDS), dtype=torch.int32)
-    check(L.hcspmm_plan_build(_ptr(rp_h), _ptr(col_h), N, E, _ptr(bp), _ptr(e2c), _ptr(ht),
+    check(L.hcspmm_plan_build(_ptr(rp_h), _ptr(col_h), N, E, M, _ptr(bp), _ptr(e2c), _ptr(ht),
                               ctypes.byref(_PLAN_PARAMS), _ptr(plan), plan.numel()))
     if on_gpu:
         rp_dev = row_pointers.to(device=dev, dtype=torch.int64)
@@ -145,13 +213,13 @@ def preprocess(column_index, row_pointers, num_nodes, num_edges, num_row_windows
                                       output_size=E)
     h = Header.from_buffer_copy(plan[:Header.WORDS].numpy().tobytes())
     outs = [t.to(dev) for t in (bp, e2c, e2r, ht, plan)]  # .to() is a no-op for the device-made e2r
-    _register(outs[4], h)
+    _register(outs[4], h, row_pointers, column_index)
     col_nzr = torch.zeros(1, dtype=torch.int32, device=dev)
     return [outs[0], outs[1], outs[2], outs[3], outs[4], col_nzr]
 
 
 def build_plan(row_pointers, column_index, blockPartition, edgeToColumn, hybrid_type, device=None,
-               split_threshold=0, segment_len=0):
+               split_threshold=0, segment_len=0, num_columns=None):
     """Launch plan for an arbitrary window classification (e.g. every window forced onto one sub-path,
     or a classifier of the caller's own): -> plan tensor to pass as `row_nzr`."""
     L = lib()
@@ -162,12 +230,12 @@ def build_plan(row_pointers, column_index, blockPartition, edgeToColumn, hybrid_
     words = ctypes.c_int64(0)
     check(L.hcspmm_plan_words(_ptr(rp_h), N, E, _ptr(bp_h), _ptr(ht_h), ctypes.byref(params), ctypes.byref(words)))
     plan = torch.empty(max(int(words.value), Header.WORDS), dtype=torch.int32)
-    check(L.hcspmm_plan_build(_ptr(rp_h), _ptr(col_h), N, E, _ptr(bp_h), _ptr(e2c_h), _ptr(ht_h), ctypes.byref(params),
-                              _ptr(plan), plan.numel()))
+    check(L.hcspmm_plan_build(_ptr(rp_h), _ptr(col_h), N, E, N if num_columns is None else int(num_columns), _ptr(bp_h),
+                              _ptr(e2c_h), _ptr(ht_h), ctypes.byref(params), _ptr(plan), plan.numel()))
     h = Header.from_buffer_copy(plan[:Header.WORDS].numpy().tobytes())
     dev = torch.device(device) if device is not None else row_pointers.device
     plan_d = plan.to(dev)
-    _register(plan_d, h)
+    _register(plan_d, h, row_pointers, column_index)
     return plan_d
 
 
@@ -177,9 +245,6 @@ def _check_input(t, name):
         raise RuntimeError("%s must be a CUDA tensor" % name)
     if not t.is_contiguous():
         raise RuntimeError("%s must be contiguous" % name)
-
-
-_VALIDATE = os.environ.get("HCSPMM_VALIDATE", "0") == "1"
 
 
 # feature element types of hcspmm_forward_typed (include/hcspmm.h HCSPMM_DTYPE_*)
@@ -198,12 +263,21 @@ def _graph_args(X, row_pointers, column_index, blockPartition, edgeToColumn, edg
     D = X.size(1)
     if X.size(0) != N and not rect:
         raise RuntimeError("input has %d rows but the graph has %d nodes" % (X.size(0), N))
-    if _VALIDATE and E > 0:  # HCSPMM_VALIDATE=1: a column id outside X would be an out-of-bounds gather on the GPU
-        lo, hi = int(column_index.min()), int(column_index.max())
-        if lo < 0 or hi >= X.size(0):
-            raise RuntimeError("column_index out of range [0, %d): min %d max %d" % (X.size(0), lo, hi))
-    h = plan_header(row_nzr, N, E) if (row_nzr is not None and row_nzr.is_cuda) else None
+    h = _checked_header(row_nzr, row_pointers, column_index, N, E, X.size(0))
     return N, E, D, h
+
+
+def _checked_header(row_nzr, row_pointers, column_index, N, E, x_rows):
+    """Header of the plan in `row_nzr` (None: the reference's placeholder -> plan-free kernel), after checking
+    that the plan belongs to THIS graph and that X has every row the plan gathers."""
+    e = _entry(row_nzr, N, E) if (row_nzr is not None and row_nzr.is_cuda) else None
+    if e is None:
+        return None
+    check(lib().hcspmm_plan_check(ctypes.byref(e.header), N, E, row_nzr.numel()))
+    if x_rows < e.header.num_columns:
+        raise RuntimeError("input has %d rows but the plan gathers from %d" % (x_rows, e.header.num_columns))
+    _verify_graph(e, row_pointers, column_index)
+    return e.header
 
 
 def _spmm(X, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, hybrid_type, row_nzr, col_nzr,
@@ -220,7 +294,7 @@ def _spmm(X, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow
             ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=X.device)
     stream = ctypes.c_void_p(torch.cuda.current_stream(X.device).cuda_stream)
     with torch.cuda.device(X.device):
-        check(L.hcspmm_forward_typed(_ptr(X), D, _ptr(Z), D, _DTYPES[X.dtype], _ptr(row_pointers), _ptr(column_index),
+        check(L.hcspmm_forward_typed(_ptr(X), X.size(0), D, _ptr(Z), D, _DTYPES[X.dtype], _ptr(row_pointers), _ptr(column_index),
                                      _ptr(blockPartition), _ptr(edgeToColumn), _ptr(edgeToRow), _ptr(hybrid_type),
                                      _ptr(row_nzr) if h is not None else ctypes.c_void_p(0),
                                      ctypes.byref(h) if h is not None else None, N, E, D, _ptr(ws), ws_bytes, stream))
@@ -243,10 +317,11 @@ def forward_rect(X_full, row_pointers, column_index, blockPartition, edgeToColum
 
 
 def forward_into(X, Z, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, hybrid_type, row_nzr,
-                 col_nzr):
+                 col_nzr, workspace=None):
     """Strided form: Z[:, :] = A @ X where X and Z may be column slices of wider matrices (unit inner
     stride, any row stride) and X may have any number of rows (column ids index them).  Used by the
-    multi-GPU shard to multiply one gathered column panel at a time straight into its slice of Z."""
+    multi-GPU shard to multiply one gathered column panel at a time straight into its slice of Z.
+    `workspace`: optional caller-kept fp32 buffer of at least workspace_bytes(row_nzr, D) bytes."""
     L = lib()
     for t, n in ((row_pointers, "nodePointer"), (column_index, "edgeList"), (blockPartition, "blockPartition"),
                  (edgeToColumn, "edgeToColumn"), (edgeToRow, "edgeToRow")):
@@ -259,15 +334,18 @@ def forward_into(X, Z, row_pointers, column_index, blockPartition, edgeToColumn,
     N, E, D = row_pointers.size(0) - 1, column_index.size(0), X.size(1)
     if Z.size(0) != N or Z.size(1) != D:
         raise RuntimeError("output must be [num_nodes, embedding_dim]")
-    h = plan_header(row_nzr, N, E) if (row_nzr is not None and row_nzr.is_cuda) else None
+    h = _checked_header(row_nzr, row_pointers, column_index, N, E, X.size(0))
     ws, ws_bytes = None, 0
     if h is not None:
         ws_bytes = int(L.hcspmm_workspace_bytes(ctypes.byref(h), D))
         if ws_bytes:
-            ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=X.device)
+            if workspace is not None and workspace.numel() * workspace.element_size() >= ws_bytes:
+                ws = workspace  # a caller-kept buffer: nothing is allocated in the step (hcspmm.sharded)
+            else:
+                ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=X.device)
     stream = ctypes.c_void_p(torch.cuda.current_stream(X.device).cuda_stream)
     with torch.cuda.device(X.device):
-        check(L.hcspmm_forward_typed(_ptr(X), X.stride(0), _ptr(Z), Z.stride(0), _DTYPES[X.dtype], _ptr(row_pointers),
+        check(L.hcspmm_forward_typed(_ptr(X), X.size(0), X.stride(0), _ptr(Z), Z.stride(0), _DTYPES[X.dtype], _ptr(row_pointers),
                                      _ptr(column_index), _ptr(blockPartition), _ptr(edgeToColumn), _ptr(edgeToRow),
                                      _ptr(hybrid_type), _ptr(row_nzr) if h is not None else ctypes.c_void_p(0),
                                      ctypes.byref(h) if h is not None else None, N, E, D, _ptr(ws), ws_bytes, stream))

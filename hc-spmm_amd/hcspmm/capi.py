@@ -16,7 +16,7 @@ OK, EINVAL, ENOMEM, EPLAN, EHIP, EWORKSPACE, ERANGE = 0, -1, -2, -3, -4, -5, -6
 
 class Header(ctypes.Structure):
     """hcspmm_plan_header (include/hcspmm.h)."""
-    WORDS = 32
+    WORDS = 64
     MAGIC = 0x48435350
     _fields_ = [(n, ctypes.c_int32) for n in (
         "magic", "version", "total_words", "num_nodes", "num_edges", "num_windows", "split_threshold", "segment_len",
@@ -24,7 +24,14 @@ class Header(ctypes.Structure):
         "off_fixups", "nnz_sparse", "nnz_dense", "uniq_dense", "max_dense_k")] + [("n_len_gt", ctypes.c_int32 * 5),
                                                                                   ("n_tiny", ctypes.c_int32), ("n_dense_compact", ctypes.c_int32),
                                                                                   ("off_dense_compact", ctypes.c_int32), ("n_dense_compact2", ctypes.c_int32),
-                                                                                  ("off_dense_compact2", ctypes.c_int32), ("reserved", ctypes.c_int32 * 2)]
+                                                                                  ("off_dense_compact2", ctypes.c_int32), ("num_columns", ctypes.c_int32),
+                                                                                  ("n_sparse_windows", ctypes.c_int32), ("off_sparse_windows", ctypes.c_int32),
+                                                                                  ("fingerprint_lo", ctypes.c_uint32), ("fingerprint_hi", ctypes.c_uint32),
+                                                                                  ("reserved", ctypes.c_int32 * 29)]
+
+    @property
+    def fingerprint(self):
+        return (int(self.fingerprint_hi) << 32) | int(self.fingerprint_lo)
 
 
 class PlanParams(ctypes.Structure):
@@ -39,17 +46,19 @@ SYMBOLS = {
     "hcspmm_strerror": (ctypes.c_char_p, [_int]),
     "hcspmm_abi_version": (_int, []),
     "hcspmm_last_hip_error": (_int, []),
-    "hcspmm_preprocess_host": (_int, [_vp, _vp, _i64, _i64, _int, _int, _vp, _vp, _vp, _vp]),
+    "hcspmm_preprocess_host": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _int, _vp, _vp, _vp, _vp]),
     "hcspmm_plan_words": (_int, [_vp, _i64, _i64, _vp, _vp, _pp, ctypes.POINTER(_i64)]),
-    "hcspmm_plan_build": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _pp, _vp, _i64]),
-    "hcspmm_plan_check": (_int, [_hp, _i64, _i64]),
+    "hcspmm_plan_build": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _pp, _vp, _i64]),
+    "hcspmm_plan_check": (_int, [_hp, _i64, _i64, _i64]),
+    "hcspmm_graph_fingerprint_host": (_int, [_vp, _vp, _i64, _i64, ctypes.POINTER(ctypes.c_uint64)]),
+    "hcspmm_graph_fingerprint_device": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "hcspmm_workspace_bytes": (_sz, [_hp, _int]),
     "hcspmm_wide_threshold": (ctypes.c_int32, [_hp, _int]),
     "hcspmm_wide_threshold_typed": (ctypes.c_int32, [_hp, _int, _int]),
-    "hcspmm_forward_typed": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _hp, _i64, _i64, _int, _vp,
+    "hcspmm_forward_typed": (_int, [_vp, _i64, _i64, _vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _hp, _i64, _i64, _int, _vp,
                                     _sz, _vp]),
     "hcspmm_forward": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _hp, _i64, _i64, _int, _vp, _sz, _vp]),
-    "hcspmm_forward_strided": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _hp, _i64, _i64, _int, _vp, _sz,
+    "hcspmm_forward_strided": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _hp, _i64, _i64, _int, _vp, _sz,
                                       _vp]),
     "hcspmm_forward_fused": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _hp,
                                     _i64, _i64, _int, _vp, _sz, _vp]),

@@ -31,38 +31,95 @@ void check_rc(int rc, const char* what) {
               hcspmm_last_hip_error(), "]");
 }
 
-// plan registry: device pointer of a plan tensor -> (tensor kept alive, host copy of the header).
+// plan registry: device pointer of a plan tensor -> host copy of its header.  Entries hold a WEAK reference:
+// they never keep a plan alive, and are valid only while the tensor they were made for lives (while it does,
+// its address cannot be handed to another tensor, so the pointer is an unambiguous key); least recently used
+// entries go first.  Each entry also lists the (nodePointer, edgeList) tensors the plan has been checked
+// against: preprocess / build_plan register the pair the plan was built from, any other pair is fingerprinted
+// on the device once (hcspmm_graph_fingerprint_device, 8-byte read-back) and refused unless it matches.
+typedef c10::weak_intrusive_ptr<c10::TensorImpl> WeakTensor;
+WeakTensor weak_of(const torch::Tensor& t) { return WeakTensor(t.getIntrusivePtr()); }
+
+struct GraphSeen {
+  const void *rp, *col;
+  WeakTensor rp_ref, col_ref;
+};
 struct PlanEntry {
-  torch::Tensor keep;
+  WeakTensor plan;
   hcspmm_plan_header header;
+  std::vector<GraphSeen> graphs;
+  uint64_t tick;
 };
 std::mutex g_mu;
 std::unordered_map<const void*, PlanEntry> g_plans;
+uint64_t g_tick = 0;
+constexpr size_t kMaxPlans = 256, kMaxGraphsPerPlan = 8;
 
-void remember(const torch::Tensor& plan, const hcspmm_plan_header& h) {
+void remember(const torch::Tensor& plan, const hcspmm_plan_header& h, const torch::Tensor* rp, const torch::Tensor* col) {
   std::lock_guard<std::mutex> lk(g_mu);
-  if (g_plans.size() >= 256) g_plans.erase(g_plans.begin());
-  g_plans[plan.data_ptr()] = PlanEntry{plan, h};
+  for (auto it = g_plans.begin(); it != g_plans.end();) it = it->second.plan.expired() ? g_plans.erase(it) : std::next(it);
+  while (g_plans.size() >= kMaxPlans) {  // least recently used
+    auto lru = g_plans.begin();
+    for (auto it = g_plans.begin(); it != g_plans.end(); ++it)
+      if (it->second.tick < lru->second.tick) lru = it;
+    g_plans.erase(lru);
+  }
+  PlanEntry e{weak_of(plan), h, {}, ++g_tick};
+  if (rp && col && rp->is_cuda()) e.graphs.push_back(GraphSeen{rp->data_ptr(), col->data_ptr(), weak_of(*rp), weak_of(*col)});
+  g_plans.insert_or_assign(plan.data_ptr(), std::move(e));
 }
 
-// Returns true and fills *h when `row_nzr` carries a plan; false for the reference's [0] placeholder.
-bool lookup(const torch::Tensor& row_nzr, int64_t N, int64_t E, hcspmm_plan_header* h) {
+// Returns true and fills *h when `row_nzr` carries a plan for THIS graph; false for the reference's [0]
+// placeholder; throws when the tensor holds a plan that belongs to another graph.
+bool lookup(const torch::Tensor& row_nzr, const torch::Tensor& nodePointer, const torch::Tensor& edgeList, int64_t N,
+            int64_t E, hcspmm_plan_header* h) {
   if (!row_nzr.defined() || !row_nzr.is_cuda() || row_nzr.scalar_type() != torch::kInt ||
       row_nzr.numel() < HCSPMM_PLAN_HEADER_WORDS || !row_nzr.is_contiguous())
     return false;
+  bool known = false, graph_ok = false;
   {
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_plans.find(row_nzr.data_ptr());
+    if (it != g_plans.end() && it->second.plan.expired()) {
+      g_plans.erase(it);
+      it = g_plans.end();
+    }
     if (it != g_plans.end()) {
+      known = true;
+      it->second.tick = ++g_tick;
       *h = it->second.header;
-      return true;
+      for (const GraphSeen& g : it->second.graphs)
+        if (g.rp == nodePointer.data_ptr() && g.col == edgeList.data_ptr() && !g.rp_ref.expired() && !g.col_ref.expired())
+          graph_ok = true;
     }
   }
-  // first sight of this tensor (e.g. a clone): one small device read
-  auto host = row_nzr.slice(0, 0, HCSPMM_PLAN_HEADER_WORDS).cpu().contiguous();
-  std::memcpy(h, host.data_ptr<int>(), sizeof(*h));
-  if (hcspmm_plan_check(h, N, E) != HCSPMM_OK) return false;
-  remember(row_nzr, *h);
+  if (!known) {  // first sight of this tensor (e.g. a clone): one small device read
+    auto host = row_nzr.slice(0, 0, HCSPMM_PLAN_HEADER_WORDS).cpu().contiguous();
+    std::memcpy(h, host.data_ptr<int>(), sizeof(*h));
+    if (h->magic != HCSPMM_PLAN_MAGIC) return false;
+  }
+  check_rc(hcspmm_plan_check(h, N, E, row_nzr.numel()), "forward(plan check)");
+  if (!graph_ok) {
+    auto fp = torch::empty({1}, row_nzr.options().dtype(torch::kLong));
+    const c10::DeviceGuard guard(row_nzr.device());
+    check_rc(hcspmm_graph_fingerprint_device(nodePointer.data_ptr<int>(), edgeList.numel() ? edgeList.data_ptr<int>() : nullptr, N,
+                                             E, reinterpret_cast<uint64_t*>(fp.data_ptr<int64_t>()),
+                                             (void*)c10::hip::getCurrentHIPStream(row_nzr.device().index()).stream()),
+             "forward(graph fingerprint)");
+    const uint64_t got = (uint64_t)fp.item<int64_t>();
+    const uint64_t want = ((uint64_t)h->fingerprint_hi << 32) | h->fingerprint_lo;
+    TORCH_CHECK(got == want, "HCSPMM.forward: plan does not match this graph (nodePointer / edgeList differ from the ones "
+                "the plan was built from) [code ", HCSPMM_EPLAN, "]");
+    if (!known) remember(row_nzr, *h, &nodePointer, &edgeList);
+    else {
+      std::lock_guard<std::mutex> lk(g_mu);
+      auto it = g_plans.find(row_nzr.data_ptr());
+      if (it != g_plans.end()) {
+        if (it->second.graphs.size() >= kMaxGraphsPerPlan) it->second.graphs.erase(it->second.graphs.begin());
+        it->second.graphs.push_back(GraphSeen{nodePointer.data_ptr(), edgeList.data_ptr(), weak_of(nodePointer), weak_of(edgeList)});
+      }
+    }
+  }
   return true;
 }
 
@@ -85,10 +142,17 @@ int feature_dtype(const torch::Tensor& t) {
   }
 }
 
+// rect: the graph is a row block whose column ids index the rows of a taller `input` (additions forward_rect /
+// forward_into); otherwise input must have exactly num_nodes rows, as in the reference.
 Call prepare(const torch::Tensor& input, const torch::Tensor& nodePointer, const torch::Tensor& edgeList,
              const torch::Tensor& blockPartition, const torch::Tensor& edgeToColumn, const torch::Tensor& edgeToRow,
-             const torch::Tensor& row_nzr, bool allow_16bit = false) {
-  CHECK_INPUT(input);
+             const torch::Tensor& row_nzr, bool allow_16bit = false, bool rect = false, bool strided = false,
+             const torch::Tensor* workspace = nullptr) {
+  if (strided) {
+    CHECK_CUDA(input);
+  } else {
+    CHECK_INPUT(input);
+  }
   CHECK_INPUT(nodePointer);
   CHECK_INPUT(edgeList);
   CHECK_INPUT(blockPartition);
@@ -102,11 +166,18 @@ Call prepare(const torch::Tensor& input, const torch::Tensor& nodePointer, const
   c.N = nodePointer.size(0) - 1;  // reference :212-214
   c.E = edgeList.size(0);
   c.D = (int)input.size(1);
-  TORCH_CHECK(input.size(0) == c.N, "input has ", input.size(0), " rows but the graph has ", c.N, " nodes");
-  c.has_plan = lookup(row_nzr, c.N, c.E, &c.header);
+  TORCH_CHECK(rect || input.size(0) == c.N, "input has ", input.size(0), " rows but the graph has ", c.N, " nodes");
+  c.has_plan = lookup(row_nzr, nodePointer, edgeList, c.N, c.E, &c.header);
   if (c.has_plan) {
+    TORCH_CHECK(input.size(0) >= c.header.num_columns, "input has ", input.size(0), " rows but the plan gathers from ",
+                c.header.num_columns);
     const size_t need = hcspmm_workspace_bytes(&c.header, c.D);
-    if (need) c.workspace = torch::empty({(int64_t)(need / 4)}, input.options().dtype(torch::kFloat));
+    if (need) {
+      if (workspace && workspace->defined() && workspace->is_cuda() && (size_t)workspace->nbytes() >= need)
+        c.workspace = *workspace;  // a caller-kept buffer: nothing is allocated in the step
+      else
+        c.workspace = torch::empty({(int64_t)(need / 4)}, input.options().dtype(torch::kFloat));
+    }
   }
   c.stream = (void*)c10::hip::getCurrentHIPStream(input.device().index()).stream();
   return c;
@@ -118,16 +189,16 @@ int* mptr(torch::Tensor& t) { return t.numel() > 0 ? t.data_ptr<int>() : nullptr
 torch::Tensor run_spmm(const torch::Tensor& input, const torch::Tensor& nodePointer, const torch::Tensor& edgeList,
                        const torch::Tensor& blockPartition, const torch::Tensor& edgeToColumn,
                        const torch::Tensor& edgeToRow, const torch::Tensor& hybrid_type,
-                       const torch::Tensor& row_nzr) {
+                       const torch::Tensor& row_nzr, bool rect = false) {
   // fp16 / bf16 features too (the paper's half-precision variants, Table VII): Z has the input's dtype
-  Call c = prepare(input, nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow, row_nzr, true);
+  Call c = prepare(input, nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow, row_nzr, true, rect);
   auto output = torch::empty({c.N, (int64_t)c.D}, input.options());  // reference K.cu:431-433
   const c10::DeviceGuard guard(input.device());
   const int rc = hcspmm_forward_typed(
-      input.data_ptr(), c.D, output.data_ptr(), c.D, feature_dtype(input), iptr(nodePointer), iptr(edgeList),
+      input.data_ptr(), input.size(0), c.D, output.data_ptr(), c.D, feature_dtype(input), iptr(nodePointer), iptr(edgeList),
       iptr(blockPartition), iptr(edgeToColumn), iptr(edgeToRow), iptr(hybrid_type), c.has_plan ? iptr(row_nzr) : nullptr,
       c.has_plan ? &c.header : nullptr, c.N, c.E, c.D, c.workspace.defined() ? c.workspace.data_ptr() : nullptr,
-      c.workspace.defined() ? (size_t)c.workspace.numel() * 4 : 0, c.stream);
+      c.workspace.defined() ? (size_t)c.workspace.nbytes() : 0, c.stream);
   check_rc(rc, "forward");
   return output;
 }
@@ -158,9 +229,20 @@ std::vector<torch::Tensor> run_fused(const torch::Tensor& input, const torch::Te
       weights.stride(0), weights.stride(1), H, iptr(nodePointer), iptr(edgeList), iptr(blockPartition),
       iptr(edgeToColumn), iptr(edgeToRow), iptr(hybrid_type), c.has_plan ? iptr(row_nzr) : nullptr,
       c.has_plan ? &c.header : nullptr, c.N, c.E, c.D, c.workspace.defined() ? c.workspace.data_ptr() : nullptr,
-      c.workspace.defined() ? (size_t)c.workspace.numel() * 4 : 0, c.stream);
+      c.workspace.defined() ? (size_t)c.workspace.nbytes() : 0, c.stream);
   check_rc(rc, "forward_fused");
   return {output, output2};
+}
+
+// large device arrays come back through a pinned buffer (a pageable D2H copy runs at ~1.4 GB/s)
+torch::Tensor to_host_i32(const torch::Tensor& t) {
+  if (t.is_cuda() && t.scalar_type() == torch::kInt && t.is_contiguous() && t.numel() > (1 << 16)) {
+    auto host = torch::empty(t.sizes(), torch::TensorOptions().dtype(torch::kInt).pinned_memory(true));
+    host.copy_(t, /*non_blocking=*/true);
+    c10::hip::getCurrentHIPStream(t.device().index()).synchronize();
+    return host;
+  }
+  return t.to(torch::kCPU, torch::kInt).contiguous();
 }
 
 }  // namespace
@@ -168,25 +250,19 @@ std::vector<torch::Tensor> run_fused(const torch::Tensor& input, const torch::Te
 // preprocess(column_index, row_pointers, num_nodes, num_edges, num_row_windows)  -- reference
 // hybrid_all.cpp:13-17 / hybrid_all_kernel.cu:339-408; note column_index comes FIRST
 // (HC-SpMM_main.py:52).  Host-side (north_star); outputs live on the device of the inputs.
+// num_columns (optional 6th argument, not in the reference whose graphs are square): rows of the matrix the
+// column ids index, for a row block of a sharded graph; ids outside [0, num_columns) are an error here rather
+// than an out-of-bounds gather on the GPU.
 std::vector<torch::Tensor> preprocess(torch::Tensor edgeList_tensor, torch::Tensor nodePointer_tensor, int num_nodes,
-                                      int edge_num, int block_num) {
+                                      int edge_num, int block_num, int64_t num_columns) {
   (void)edge_num;  // the reference's count is the raw line count (dataset.py:59); the tensor size is used
   auto dev = edgeList_tensor.device();
-  // large device arrays come back through a pinned buffer (a pageable D2H copy runs at ~1.4 GB/s)
-  auto to_host = [](const torch::Tensor& t) {
-    if (t.is_cuda() && t.scalar_type() == torch::kInt && t.is_contiguous() && t.numel() > (1 << 16)) {
-      auto host = torch::empty(t.sizes(), torch::TensorOptions().dtype(torch::kInt).pinned_memory(true));
-      host.copy_(t, /*non_blocking=*/true);
-      c10::hip::getCurrentHIPStream(t.device().index()).synchronize();
-      return host;
-    }
-    return t.to(torch::kCPU, torch::kInt).contiguous();
-  };
-  auto col = to_host(edgeList_tensor);
-  auto rp = to_host(nodePointer_tensor);
+  auto col = to_host_i32(edgeList_tensor);
+  auto rp = to_host_i32(nodePointer_tensor);
   const int64_t N = rp.numel() - 1, E = col.numel(), W = (N + HCSPMM_BLK_H - 1) / HCSPMM_BLK_H;
   TORCH_CHECK(num_nodes == N, "preprocess: num_nodes (", num_nodes, ") != row_pointers.size(0)-1 (", N, ")");
   TORCH_CHECK(block_num == W, "preprocess: num_row_windows (", block_num, ") != ceil(N/16) (", W, ")");
+  const int64_t M = num_columns > 0 ? num_columns : N;
   auto opts = torch::TensorOptions().dtype(torch::kInt);
   auto bp = torch::empty({W}, opts), ht = torch::empty({W}, opts), e2c = torch::empty({E}, opts);
   // edgeToRow is the plain CSR row expansion (reference fill_edgeToRow, K.cu:314-326): made on the
@@ -199,19 +275,19 @@ std::vector<torch::Tensor> preprocess(torch::Tensor edgeList_tensor, torch::Tens
   } else {
     e2r = torch::empty({E}, opts);
   }
-  check_rc(hcspmm_preprocess_host(rp.data_ptr<int>(), iptr(col), N, E, g_rule, 0, mptr(bp), mptr(e2c),
+  check_rc(hcspmm_preprocess_host(rp.data_ptr<int>(), iptr(col), N, E, M, g_rule, 0, mptr(bp), mptr(e2c),
                                   dev.is_cuda() ? nullptr : mptr(e2r), mptr(ht)),
            "preprocess");
   int64_t words = 0;
   check_rc(hcspmm_plan_words(rp.data_ptr<int>(), N, E, iptr(bp), iptr(ht), &g_params, &words), "preprocess(plan size)");
   auto plan = torch::empty({std::max<int64_t>(words, HCSPMM_PLAN_HEADER_WORDS)}, opts);
-  check_rc(hcspmm_plan_build(rp.data_ptr<int>(), iptr(col), N, E, iptr(bp), iptr(e2c), iptr(ht), &g_params,
+  check_rc(hcspmm_plan_build(rp.data_ptr<int>(), iptr(col), N, E, M, iptr(bp), iptr(e2c), iptr(ht), &g_params,
                              plan.data_ptr<int>(), plan.numel()),
            "preprocess(plan build)");
   hcspmm_plan_header h;
   std::memcpy(&h, plan.data_ptr<int>(), sizeof(h));
   auto plan_d = plan.to(dev);
-  if (plan_d.is_cuda()) remember(plan_d, h);
+  if (plan_d.is_cuda()) remember(plan_d, h, &nodePointer_tensor, &edgeList_tensor);
   auto col_nzr = torch::zeros({1}, opts).to(dev);  // stays the reference's placeholder (K.cu:405)
   return {bp.to(dev), e2c.to(dev), e2r.to(dev), ht.to(dev), plan_d, col_nzr};
 }
@@ -240,8 +316,64 @@ std::vector<torch::Tensor> spmm_forward_final_fused(HCSPMM_GRAPH_PARAMS, torch::
                    weights, output);
 }
 
+// ---- additions (not in the reference): the row-block forms the multi-GPU shard uses --------------------------
+// forward_rect: A is num_nodes x M, column ids index the rows of X_full (M x D, the all-gathered embedding matrix)
+std::vector<torch::Tensor> spmm_forward_rect(HCSPMM_GRAPH_PARAMS) {
+  return {run_spmm(input, nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow, hybrid_type, row_nzr, true)};
+}
+
+// forward_into: Z[:, :] = A @ X on strided views (unit inner stride, any row stride): a column panel of a wider
+// matrix is read / written in place.  `workspace`: optional caller-kept fp32 buffer (plan_info()["workspace_floats_per_column"]
+// * D floats) so that a step allocates nothing.
+torch::Tensor spmm_forward_into(torch::Tensor input, torch::Tensor output, torch::Tensor nodePointer, torch::Tensor edgeList,
+                                torch::Tensor blockPartition, torch::Tensor edgeToColumn, torch::Tensor edgeToRow,
+                                torch::Tensor hybrid_type, torch::Tensor row_nzr, torch::Tensor col_nzr,
+                                c10::optional<torch::Tensor> workspace) {
+  (void)col_nzr;
+  for (const torch::Tensor* t : {&input, &output}) {
+    TORCH_CHECK(t->is_cuda() && feature_dtype(*t) >= 0 && t->scalar_type() == input.scalar_type() && t->dim() == 2 &&
+                    t->stride(1) == 1 && t->stride(0) >= t->size(1),
+                t == &input ? "input" : "output", " must be a 2-D float32 / float16 / bfloat16 view with unit inner stride");
+  }
+  torch::Tensor ws = workspace.has_value() ? *workspace : torch::Tensor();
+  Call c = prepare(input, nodePointer, edgeList, blockPartition, edgeToColumn, edgeToRow, row_nzr, true, true, true, &ws);
+  TORCH_CHECK(output.size(0) == c.N && output.size(1) == c.D, "output must be [num_nodes, embedding_dim]");
+  const c10::DeviceGuard guard(input.device());
+  const int rc = hcspmm_forward_typed(
+      input.data_ptr(), input.size(0), input.stride(0), output.data_ptr(), output.stride(0), feature_dtype(input),
+      iptr(nodePointer), iptr(edgeList), iptr(blockPartition), iptr(edgeToColumn), iptr(edgeToRow), iptr(hybrid_type),
+      c.has_plan ? iptr(row_nzr) : nullptr, c.has_plan ? &c.header : nullptr, c.N, c.E, c.D,
+      c.workspace.defined() ? c.workspace.data_ptr() : nullptr, c.workspace.defined() ? (size_t)c.workspace.nbytes() : 0,
+      c.stream);
+  check_rc(rc, "forward_into");
+  return output;
+}
+
+// build_plan: launch plan for an arbitrary window classification (e.g. every window forced onto one sub-path)
+torch::Tensor build_plan(torch::Tensor row_pointers, torch::Tensor column_index, torch::Tensor blockPartition,
+                         torch::Tensor edgeToColumn, torch::Tensor hybrid_type, int split_threshold, int segment_len,
+                         int64_t num_columns) {
+  auto rp = to_host_i32(row_pointers), col = to_host_i32(column_index), bp = to_host_i32(blockPartition),
+       e2c = to_host_i32(edgeToColumn), ht = to_host_i32(hybrid_type);
+  const int64_t N = rp.numel() - 1, E = col.numel();
+  hcspmm_plan_params pp = (split_threshold || segment_len) ? hcspmm_plan_params{split_threshold, segment_len} : g_params;
+  int64_t words = 0;
+  check_rc(hcspmm_plan_words(rp.data_ptr<int>(), N, E, iptr(bp), iptr(ht), &pp, &words), "build_plan(plan size)");
+  auto plan = torch::empty({std::max<int64_t>(words, HCSPMM_PLAN_HEADER_WORDS)}, torch::TensorOptions().dtype(torch::kInt));
+  check_rc(hcspmm_plan_build(rp.data_ptr<int>(), iptr(col), N, E, num_columns > 0 ? num_columns : N, iptr(bp), iptr(e2c),
+                             iptr(ht), &pp, plan.data_ptr<int>(), plan.numel()),
+           "build_plan");
+  hcspmm_plan_header h;
+  std::memcpy(&h, plan.data_ptr<int>(), sizeof(h));
+  auto plan_d = plan.to(row_pointers.device());
+  if (plan_d.is_cuda()) remember(plan_d, h, &row_pointers, &column_index);
+  return plan_d;
+}
+
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
-  m.def("preprocess", &preprocess, "Preprocess step: window condensing + classifier + MI355X launch plan (host)");
+  m.def("preprocess", &preprocess, "Preprocess step: window condensing + classifier + MI355X launch plan (host)",
+        pybind11::arg("column_index"), pybind11::arg("row_pointers"), pybind11::arg("num_nodes"), pybind11::arg("num_edges"),
+        pybind11::arg("num_row_windows"), pybind11::arg("num_columns") = -1);
   // forward computation (names of reference hybrid_all.cpp:504-512)
   m.def("forward", &spmm_forward, "HCSPMM SPMM forward (gfx950)");
   m.def("forward_more", &spmm_forward, "HCSPMM SPMM forward more (gfx950)");
@@ -261,7 +393,29 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("backward_fixed64_fused", &spmm_forward_fused, "HCSPMM SPMM backward fixed 64 fused (gfx950)");
   m.def("backward_final_fused_64", &spmm_forward_final_fused, "HCSPMM SPMM backward final fused 64 (gfx950)");
   m.def("backward_GIN_final_fused", &spmm_forward_fused, "HCSPMM SPMM backward for GIN final fused (gfx950)");
-  // additions (not in the reference): classifier rule / plan tunables, LOI reorder on the host
+  // additions (not in the reference): row-block forms, plans for a caller's classification, classifier rule /
+  // plan tunables, LOI reorder on the host
+  m.def("forward_rect", &spmm_forward_rect, "A (n x M row block) * X_full (M x D) -> [Z (n x D)]");
+  m.def("forward_into", &spmm_forward_into, "Z_view[:, :] = A @ X_view on strided column panels",
+        pybind11::arg("input"), pybind11::arg("output"), pybind11::arg("nodePointer"), pybind11::arg("edgeList"),
+        pybind11::arg("blockPartition"), pybind11::arg("edgeToColumn"), pybind11::arg("edgeToRow"),
+        pybind11::arg("hybrid_type"), pybind11::arg("row_nzr"), pybind11::arg("col_nzr"),
+        pybind11::arg("workspace") = pybind11::none());
+  m.def("build_plan", &build_plan, "launch plan (row_nzr) for a caller-supplied window classification",
+        pybind11::arg("row_pointers"), pybind11::arg("column_index"), pybind11::arg("blockPartition"),
+        pybind11::arg("edgeToColumn"), pybind11::arg("hybrid_type"), pybind11::arg("split_threshold") = 0,
+        pybind11::arg("segment_len") = 0, pybind11::arg("num_columns") = -1);
+  m.def("wide_threshold", [](torch::Tensor row_nzr, int embedding_dim, int dtype) {
+    hcspmm_plan_header h;
+    bool has = false;
+    if (row_nzr.defined() && row_nzr.numel() >= HCSPMM_PLAN_HEADER_WORDS && row_nzr.scalar_type() == torch::kInt) {
+      auto host = row_nzr.slice(0, 0, HCSPMM_PLAN_HEADER_WORDS).cpu().contiguous();
+      std::memcpy(&h, host.data_ptr<int>(), sizeof(h));
+      has = h.magic == HCSPMM_PLAN_MAGIC;
+    }
+    return (int64_t)hcspmm_wide_threshold_typed(has ? &h : nullptr, embedding_dim, dtype);
+  }, "rows with more entries than this are summed by a whole wave (hcspmm.h hcspmm_wide_threshold_typed)",
+        pybind11::arg("row_nzr"), pybind11::arg("embedding_dim"), pybind11::arg("dtype") = 0);
   m.def("set_rule", [](int rule) {
     TORCH_CHECK(rule >= HCSPMM_RULE_INTENDED && rule <= HCSPMM_RULE_MI355X_WIDE, "unknown rule");
     g_rule = rule;
@@ -322,6 +476,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     d["n_tasks"] = h.n_tasks; d["n_dense"] = h.n_dense; d["n_split_rows"] = h.n_split_rows;
     d["n_partials"] = h.n_partials; d["nnz_sparse"] = h.nnz_sparse; d["nnz_dense"] = h.nnz_dense;
     d["uniq_dense"] = h.uniq_dense; d["split_threshold"] = h.split_threshold; d["segment_len"] = h.segment_len;
+    d["max_dense_k"] = h.max_dense_k; d["n_tiny"] = h.n_tiny; d["n_dense_compact"] = h.n_dense_compact;
+    d["n_dense_compact2"] = h.n_dense_compact2; d["num_columns"] = h.num_columns;
+    d["n_sparse_windows"] = h.n_sparse_windows; d["num_nodes"] = h.num_nodes; d["num_edges"] = h.num_edges;
+    d["fingerprint"] = ((uint64_t)h.fingerprint_hi << 32) | h.fingerprint_lo;
     return d;
   }, "fields of the launch plan carried in row_nzr ({} for the reference's [0] placeholder)");
 }

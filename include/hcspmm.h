@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HCSPMM_ABI_VERSION 1
+#define HCSPMM_ABI_VERSION 2
 
 /* Row-window geometry: hybrid_kernel/config.h:4-5 (BLK_H 16, BLK_W 8). */
 #define HCSPMM_BLK_H 16
@@ -31,9 +31,9 @@ extern "C" {
 
 /* return codes */
 #define HCSPMM_OK 0
-#define HCSPMM_EINVAL (-1)     /* bad argument (null pointer, negative size, D <= 0, ...) */
+#define HCSPMM_EINVAL (-1)     /* bad argument (null pointer, negative size, D <= 0, a column id outside [0, num_columns), ...) */
 #define HCSPMM_ENOMEM (-2)     /* host allocation failed */
-#define HCSPMM_EPLAN (-3)      /* plan blob does not match this graph / wrong magic or version */
+#define HCSPMM_EPLAN (-3)      /* plan blob does not match this graph (magic, version, N, E, section bounds, fingerprint) */
 #define HCSPMM_EHIP (-4)       /* a HIP runtime call or kernel launch failed (hcspmm_last_hip_error) */
 #define HCSPMM_EWORKSPACE (-5) /* workspace smaller than hcspmm_workspace_bytes() */
 #define HCSPMM_ERANGE (-6)     /* a size exceeds what the int32 index contract can address */
@@ -60,14 +60,20 @@ int hcspmm_last_hip_error(void);
  * generate_edgetocolumn K.cu:242-269.  Integer outputs are bit-exact with the reference
  * algorithm (Appendix A of SURVEY.md); empty windows get blockPartition = hybrid_type = 0.
  *   row_pointers_h[N+1], column_index_h[E] : CSR, columns ascending & unique within a row
+ *   num_columns : rows of the matrix the column ids index (the reference's graphs are square: pass num_nodes, or
+ *                 <= 0 for the same); a multi-GPU row block passes the height of the gathered embedding matrix.
+ *                 Every column id is checked against [0, num_columns) -- HCSPMM_EINVAL otherwise -- so that a
+ *                 malformed CSR is an error here instead of an out-of-bounds gather on the GPU (the reference
+ *                 checks nothing).
  *   blockPartition_h[W], hybrid_type_h[W], edgeToColumn_h[E], edgeToRow_h[E] : outputs, W = ceil(N/16)
  *   num_threads <= 0 : HCSPMM_THREADS if set, else min(64, host hardware threads); the outputs do not depend on it.
  *   edgeToRow_h may be NULL (not produced): it is the plain CSR row expansion, which a caller whose
  *   graph lives in HBM can generate there without a host round trip.
  * ---------------------------------------------------------------------------------------- */
 int hcspmm_preprocess_host(const int32_t* row_pointers_h, const int32_t* column_index_h, int64_t num_nodes,
-                           int64_t num_edges, int rule, int num_threads, int32_t* blockPartition_h,
-                           int32_t* edgeToColumn_h, int32_t* edgeToRow_h, int32_t* hybrid_type_h);
+                           int64_t num_edges, int64_t num_columns, int rule, int num_threads,
+                           int32_t* blockPartition_h, int32_t* edgeToColumn_h, int32_t* edgeToRow_h,
+                           int32_t* hybrid_type_h);
 
 /* ------------------------------------------------------------------------------------------
  * Launch plan (host build, device resident).  New on MI355X: the reference branches per thread
@@ -83,13 +89,13 @@ int hcspmm_preprocess_host(const int32_t* row_pointers_h, const int32_t* column_
  * read-back).
  * ---------------------------------------------------------------------------------------- */
 #define HCSPMM_PLAN_MAGIC 0x48435350 /* "HCSP" */
-#define HCSPMM_PLAN_VERSION 5
+#define HCSPMM_PLAN_VERSION 6
 #define HCSPMM_TINY_LEN 2 /* tasks of at most this many entries carry their indices in the descriptor */
 #define HCSPMM_COMPACT_K 40     /* dense windows of at most this many (padded) columns use compact records ... */
 #define HCSPMM_COMPACT_WORDS 64 /* ... of this many words: [window, K/4, U[40], 10 x (mask lo, mask hi), pad] */
 #define HCSPMM_COMPACT2_K 80    /* wider windows up to this many (padded) columns use double records ... */
 #define HCSPMM_COMPACT2_WORDS 128 /* ... of this many words: [window, K/4, U[80], 20 x (mask lo, mask hi), pad] */
-#define HCSPMM_PLAN_HEADER_WORDS 32
+#define HCSPMM_PLAN_HEADER_WORDS 64
 
 typedef struct hcspmm_plan_header {
   int32_t magic;            /* HCSPMM_PLAN_MAGIC */
@@ -123,7 +129,13 @@ typedef struct hcspmm_plan_header {
   int32_t n_dense_compact2; /* the n_dense_compact2 dense windows before them have HCSPMM_COMPACT_K < K <= HCSPMM_COMPACT2_K
                                and live in HCSPMM_COMPACT2_WORDS-word records of the same layout (U[80], 20 masks) */
   int32_t off_dense_compact2; /* word offset of those records (a multiple of 64) */
-  int32_t reserved[2];
+  int32_t num_columns;      /* rows of X this plan gathers from: every column id it holds or refers to is < this */
+  int32_t n_sparse_windows; /* row windows NOT on the dense-tile path (sparse-row and empty ones), ... */
+  int32_t off_sparse_windows; /* ... their ids, ascending: the 16-row tiles the update pass of
+                               hcspmm_forward_fused still has to multiply by the weights */
+  uint32_t fingerprint_lo;  /* hcspmm_graph_fingerprint_host(row_pointers, column_index) of the graph the plan was */
+  uint32_t fingerprint_hi;  /* built from: a plan for another graph with the same N and E is told apart by it */
+  int32_t reserved[29];
 } hcspmm_plan_header;
 
 /* Tunables for the plan; zero-initialise for defaults. */
@@ -137,14 +149,31 @@ int hcspmm_plan_words(const int32_t* row_pointers_h, int64_t num_nodes, int64_t 
                       const int32_t* blockPartition_h, const int32_t* hybrid_type_h,
                       const hcspmm_plan_params* params, int64_t* words_out);
 
-/* Fill plan_h[words] (host).  The caller uploads it to HBM unchanged. */
+/* Fill plan_h[words] (host).  The caller uploads it to HBM unchanged.  num_columns as for
+ * hcspmm_preprocess_host (<= 0: num_nodes); column ids are range-checked here too (HCSPMM_EINVAL), since a plan
+ * may be built for a classification that did not come from hcspmm_preprocess_host. */
 int hcspmm_plan_build(const int32_t* row_pointers_h, const int32_t* column_index_h, int64_t num_nodes,
-                      int64_t num_edges, const int32_t* blockPartition_h, const int32_t* edgeToColumn_h,
-                      const int32_t* hybrid_type_h, const hcspmm_plan_params* params, int32_t* plan_h,
-                      int64_t words);
+                      int64_t num_edges, int64_t num_columns, const int32_t* blockPartition_h,
+                      const int32_t* edgeToColumn_h, const int32_t* hybrid_type_h, const hcspmm_plan_params* params,
+                      int32_t* plan_h, int64_t words);
 
-/* Validate a header against (N, E); HCSPMM_OK or HCSPMM_EPLAN. */
-int hcspmm_plan_check(const hcspmm_plan_header* header_h, int64_t num_nodes, int64_t num_edges);
+/* Validate a header against (N, E) and its own section layout (every section inside total_words, counts
+ * consistent); plan_words_available = length of the buffer that holds the blob (<= 0: not checked).
+ * HCSPMM_OK or HCSPMM_EPLAN. */
+int hcspmm_plan_check(const hcspmm_plan_header* header_h, int64_t num_nodes, int64_t num_edges,
+                      int64_t plan_words_available);
+
+/* 64-bit fingerprint of a CSR graph: an order-independent sum of mixed (index, value) pairs over row_pointers
+ * and column_index, so host threads and GPU waves can each add their share.  hcspmm_plan_build stores it in the
+ * header; a binding that is handed a plan together with graph tensors it has not seen with that plan computes
+ * the device variant once (one small kernel + an 8-byte read-back, then cached by the caller) and refuses a
+ * mismatch with HCSPMM_EPLAN: a plan built for a different graph with the same N and E (e.g. the same graph
+ * after a LOI reorder) would otherwise silently produce a wrong Z.
+ *   fingerprint_out_d : 8-byte device buffer, overwritten (zeroed on `stream` first). */
+int hcspmm_graph_fingerprint_host(const int32_t* row_pointers_h, const int32_t* column_index_h, int64_t num_nodes,
+                                  int64_t num_edges, uint64_t* fingerprint_out_h);
+int hcspmm_graph_fingerprint_device(const int32_t* row_pointers_d, const int32_t* column_index_d, int64_t num_nodes,
+                                    int64_t num_edges, uint64_t* fingerprint_out_d, void* stream);
 
 /* Bytes of device workspace hcspmm_forward* needs for this plan and embedding_dim (may be 0). */
 size_t hcspmm_workspace_bytes(const hcspmm_plan_header* header_h, int embedding_dim);
@@ -184,8 +213,12 @@ int hcspmm_forward(const float* X_d, float* Z_d, const int32_t* row_pointers_d, 
 
 /* The same product on strided views: X rows are ldx elements apart, Z rows ldz (both >= embedding_dim),
  * so a column panel of a wider matrix can be read / written in place (the multi-GPU shard gathers X
- * panel by panel and writes each panel's product straight into its slice of Z). */
-int hcspmm_forward_strided(const float* X_d, int64_t ldx, float* Z_d, int64_t ldz, const int32_t* row_pointers_d,
+ * panel by panel and writes each panel's product straight into its slice of Z).
+ * x_rows = rows of X (hcspmm_forward: num_nodes -- the reference's graphs are square); with a plan, a launch
+ * whose plan gathers beyond it (header num_columns > x_rows) is refused with HCSPMM_EINVAL.  The plan-free
+ * kernel reads column_index as it is handed over, like the reference: its caller vouches for the range
+ * (hcspmm_preprocess_host checked it when it produced the window tensors). */
+int hcspmm_forward_strided(const float* X_d, int64_t x_rows, int64_t ldx, float* Z_d, int64_t ldz, const int32_t* row_pointers_d,
                            const int32_t* column_index_d, const int32_t* blockPartition_d,
                            const int32_t* edgeToColumn_d, const int32_t* edgeToRow_d, const int32_t* hybrid_type_d,
                            const int32_t* plan_d, const hcspmm_plan_header* plan_header_h, int64_t num_nodes,
@@ -203,7 +236,7 @@ int hcspmm_forward_strided(const float* X_d, int64_t ldx, float* Z_d, int64_t ld
  * widened exactly, summed in fp32 in the same order as the fp32 path, and rounded once (to nearest even) per
  * output element:  Z = round_dtype(fp32 sum).  The workspace is fp32 whatever the dtype
  * (hcspmm_workspace_bytes).  dtype = HCSPMM_DTYPE_F32 is hcspmm_forward_strided. */
-int hcspmm_forward_typed(const void* X_d, int64_t ldx, void* Z_d, int64_t ldz, int dtype,
+int hcspmm_forward_typed(const void* X_d, int64_t x_rows, int64_t ldx, void* Z_d, int64_t ldz, int dtype,
                          const int32_t* row_pointers_d, const int32_t* column_index_d,
                          const int32_t* blockPartition_d, const int32_t* edgeToColumn_d, const int32_t* edgeToRow_d,
                          const int32_t* hybrid_type_d, const int32_t* plan_d, const hcspmm_plan_header* plan_header_h,

@@ -64,16 +64,16 @@ int main() {
   }
   const int64_t E = (int64_t)col.size(), W = (N + 15) / 16;
   std::vector<int32_t> bp(W), ht(W), e2c(E), e2r(E);
-  HC_OK(hcspmm_preprocess_host(rowptr.data(), col.data(), N, E, HCSPMM_RULE_INTENDED, 2, bp.data(), e2c.data(), e2r.data(),
+  HC_OK(hcspmm_preprocess_host(rowptr.data(), col.data(), N, E, N, HCSPMM_RULE_INTENDED, 2, bp.data(), e2c.data(), e2r.data(),
                                ht.data()));
   int64_t words = 0;
   hcspmm_plan_params pp = {256, 128};  // make the hub row split
   HC_OK(hcspmm_plan_words(rowptr.data(), N, E, bp.data(), ht.data(), &pp, &words));
   std::vector<int32_t> plan((size_t)words);
-  HC_OK(hcspmm_plan_build(rowptr.data(), col.data(), N, E, bp.data(), e2c.data(), ht.data(), &pp, plan.data(), words));
+  HC_OK(hcspmm_plan_build(rowptr.data(), col.data(), N, E, N, bp.data(), e2c.data(), ht.data(), &pp, plan.data(), words));
   hcspmm_plan_header header;
   std::memcpy(&header, plan.data(), sizeof(header));
-  HC_OK(hcspmm_plan_check(&header, N, E));
+  HC_OK(hcspmm_plan_check(&header, N, E, words));
   if (header.n_dense == 0 || header.n_tasks == 0 || header.n_split_rows != 1) {
     std::fprintf(stderr, "unexpected plan: dense %d tasks %d split %d\n", header.n_dense, header.n_tasks, header.n_split_rows);
     return 4;
@@ -127,7 +127,7 @@ int main() {
     HIP_OK(hipMalloc(&Z16_d, sizeof(uint16_t) * X.size()));
     for (int pass = 0; pass < 2; ++pass) {
       HIP_OK(hipMemsetAsync(Z16_d, 0xff, sizeof(uint16_t) * X.size(), stream));
-      HC_OK(hcspmm_forward_typed(X16_d, D, Z16_d, D, HCSPMM_DTYPE_BF16, rp_d, col_d, bp_d, e2c_d, e2r_d, ht_d,
+      HC_OK(hcspmm_forward_typed(X16_d, N, D, Z16_d, D, HCSPMM_DTYPE_BF16, rp_d, col_d, bp_d, e2c_d, e2r_d, ht_d,
                                  pass == 0 ? plan_d : nullptr, pass == 0 ? &header : nullptr, N, E, D,
                                  pass == 0 ? ws_d : nullptr, pass == 0 ? ws_bytes : 0, (void*)stream));
       HIP_OK(hipMemcpyAsync(got16.data(), Z16_d, sizeof(uint16_t) * got16.size(), hipMemcpyDeviceToHost, stream));
@@ -138,7 +138,7 @@ int main() {
           return 8;
         }
     }
-    if (hcspmm_forward_typed(X16_d, D, Z16_d, D, 7, rp_d, col_d, bp_d, e2c_d, e2r_d, ht_d, plan_d, &header, N, E, D, ws_d,
+    if (hcspmm_forward_typed(X16_d, N, D, Z16_d, D, 7, rp_d, col_d, bp_d, e2c_d, e2r_d, ht_d, plan_d, &header, N, E, D, ws_d,
                              ws_bytes, stream) != HCSPMM_EINVAL)
       return 9;
   }
@@ -149,6 +149,45 @@ int main() {
   if (ws_bytes && hcspmm_forward(X_d, Z_d, rp_d, col_d, bp_d, e2c_d, e2r_d, ht_d, plan_d, &header, N, E, D, nullptr, 0, stream) !=
                       HCSPMM_EWORKSPACE)
     return 7;
+  // a column id outside [0, num_columns) is refused on the host (it would be an out-of-bounds gather on the GPU)
+  {
+    std::vector<int32_t> bad_col = col;
+    bad_col[E / 2] = (int32_t)N;  // one past the last row of X
+    std::vector<int32_t> bp2(W), ht2(W), e2c2(E);
+    if (hcspmm_preprocess_host(rowptr.data(), bad_col.data(), N, E, N, HCSPMM_RULE_INTENDED, 2, bp2.data(), e2c2.data(), nullptr,
+                               ht2.data()) != HCSPMM_EINVAL)
+      return 10;
+    std::vector<int32_t> plan2((size_t)words);
+    if (hcspmm_plan_build(rowptr.data(), bad_col.data(), N, E, N, bp.data(), e2c.data(), ht.data(), &pp, plan2.data(), words) !=
+        HCSPMM_EINVAL)
+      return 11;
+    // ... while the same id is fine for a row block whose columns index a taller X (num_columns = 2N)
+    if (hcspmm_plan_build(rowptr.data(), bad_col.data(), N, E, 2 * N, bp.data(), e2c.data(), ht.data(), &pp, plan2.data(), words) !=
+        HCSPMM_OK)
+      return 12;
+    hcspmm_plan_header h2;
+    std::memcpy(&h2, plan2.data(), sizeof(h2));
+    // and a launch with that plan over an X of only N rows is refused before anything is enqueued
+    if (h2.num_columns != 2 * N ||
+        hcspmm_forward_strided(X_d, N, D, Z_d, D, rp_d, col_d, bp_d, e2c_d, e2r_d, ht_d, plan_d, &h2, N, E, D, ws_d, ws_bytes,
+                               stream) != HCSPMM_EINVAL)
+      return 13;
+  }
+  // the device fingerprint of the uploaded graph equals the host one stored in the plan header
+  {
+    uint64_t host_fp = 0, dev_fp = 0, *fp_d = nullptr;
+    HC_OK(hcspmm_graph_fingerprint_host(rowptr.data(), col.data(), N, E, &host_fp));
+    HIP_OK(hipMalloc(&fp_d, sizeof(uint64_t)));
+    HC_OK(hcspmm_graph_fingerprint_device(rp_d, col_d, N, E, fp_d, (void*)stream));
+    HIP_OK(hipMemcpyAsync(&dev_fp, fp_d, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    const uint64_t in_header = ((uint64_t)header.fingerprint_hi << 32) | header.fingerprint_lo;
+    if (host_fp != dev_fp || host_fp != in_header) {
+      std::fprintf(stderr, "fingerprint mismatch: host %llx device %llx header %llx\n", (unsigned long long)host_fp,
+                   (unsigned long long)dev_fp, (unsigned long long)in_header);
+      return 14;
+    }
+  }
   std::printf("capi_smoke ok: N=%lld E=%lld dense_windows=%d tasks=%d split_rows=%d\n", (long long)N, (long long)E,
               header.n_dense, header.n_tasks, header.n_split_rows);
   return 0;

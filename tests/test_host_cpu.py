@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(capi):
     L = capi.lib()
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.hcspmm_abi_version() == 1
+    assert L.hcspmm_abi_version() == 2
     assert ctypes.sizeof(Header) == 4 * Header.WORDS
 
 
@@ -58,11 +58,11 @@ def test_forward_argument_checks_need_no_gpu(capi):
     one = np.zeros(4, np.int32)
     p = ctypes.c_void_p(one.ctypes.data)
     common = (z, z, z, z, z, z, z, None)  # graph arrays, plan, header
-    assert L.hcspmm_forward_typed(p, 4, p, 4, 7, *common, 1, 0, 4, z, 0, z) == capi.EINVAL      # unknown dtype
-    assert L.hcspmm_forward_typed(p, 4, p, 4, 0, *common, -1, 0, 4, z, 0, z) == capi.EINVAL     # negative N
-    assert L.hcspmm_forward_typed(p, 2, p, 4, 0, *common, 1, 0, 4, z, 0, z) == capi.EINVAL      # ldx < D
-    assert L.hcspmm_forward_typed(p, 4, p, 4, 2, *common, 0, 0, 4, z, 0, z) == 0                # N == 0: nothing to do
-    assert L.hcspmm_forward_typed(z, 4, p, 4, 1, *common, 1, 0, 4, z, 0, z) == capi.EINVAL      # null X
+    assert L.hcspmm_forward_typed(p, 1, 4, p, 4, 7, *common, 1, 0, 4, z, 0, z) == capi.EINVAL      # unknown dtype
+    assert L.hcspmm_forward_typed(p, 1, 4, p, 4, 0, *common, -1, 0, 4, z, 0, z) == capi.EINVAL     # negative N
+    assert L.hcspmm_forward_typed(p, 1, 2, p, 4, 0, *common, 1, 0, 4, z, 0, z) == capi.EINVAL      # ldx < D
+    assert L.hcspmm_forward_typed(p, 1, 4, p, 4, 2, *common, 0, 0, 4, z, 0, z) == 0                # N == 0: nothing to do
+    assert L.hcspmm_forward_typed(z, 1, 4, p, 4, 1, *common, 1, 0, 4, z, 0, z) == capi.EINVAL      # null X
     assert L.hcspmm_wide_threshold_typed(None, 128, 9) == 2**31 - 1
     assert L.hcspmm_wide_threshold_typed(None, 32, 0) == 64 and L.hcspmm_wide_threshold_typed(None, 256, 0) == 2**31 - 1
     assert L.hcspmm_wide_threshold_typed(None, 256, 2) == 64  # 16-bit rows of 256 columns still fit 32 lanes
@@ -105,7 +105,7 @@ def test_preprocess_multithreaded_equals_single(capi):
     for threads in (1, 7):
         bp, ht = np.zeros(W, np.int32), np.zeros(W, np.int32)
         e2c, e2r = np.zeros(E, np.int32), np.zeros(E, np.int32)
-        rc = capi.lib().hcspmm_preprocess_host(rp.ctypes.data, col.ctypes.data, N, E, 0, threads, bp.ctypes.data,
+        rc = capi.lib().hcspmm_preprocess_host(rp.ctypes.data, col.ctypes.data, N, E, N, 0, threads, bp.ctypes.data,
                                                e2c.ctypes.data, e2r.ctypes.data, ht.ctypes.data)
         assert rc == 0
         outs.append((bp, e2c, e2r, ht))
@@ -118,11 +118,11 @@ def test_preprocess_rejects_bad_arguments(capi):
     rp = np.array([0, 2, 1], np.int32)  # not monotone
     col = np.array([0], np.int32)
     out = np.zeros(4, np.int32)
-    assert L.hcspmm_preprocess_host(rp.ctypes.data, col.ctypes.data, 2, 1, 0, 1, out.ctypes.data, out.ctypes.data,
+    assert L.hcspmm_preprocess_host(rp.ctypes.data, col.ctypes.data, 2, 1, 0, 0, 1, out.ctypes.data, out.ctypes.data,
                                     out.ctypes.data, out.ctypes.data) == capi.EINVAL
-    assert L.hcspmm_preprocess_host(None, None, 2, 1, 0, 1, None, None, None, None) == capi.EINVAL
+    assert L.hcspmm_preprocess_host(None, None, 2, 1, 0, 0, 1, None, None, None, None) == capi.EINVAL
     rp = np.array([0, 1], np.int32)
-    assert L.hcspmm_preprocess_host(rp.ctypes.data, col.ctypes.data, 1, 1, 9, 1, out.ctypes.data, out.ctypes.data,
+    assert L.hcspmm_preprocess_host(rp.ctypes.data, col.ctypes.data, 1, 1, 0, 9, 1, out.ctypes.data, out.ctypes.data,
                                     out.ctypes.data, out.ctypes.data) == capi.EINVAL  # unknown rule
     with pytest.raises(RuntimeError, match="num_row_windows"):
         hcspmm.preprocess(_t(col), _t(rp), 1, 1, 5)
@@ -301,10 +301,109 @@ def test_plan_check_rejects_mismatch(capi):
     plan = _pre(rp, col)[4].numpy()
     h = Header.from_buffer_copy(plan[:Header.WORDS].tobytes())
     L = capi.lib()
-    assert L.hcspmm_plan_check(ctypes.byref(h), len(rp) - 1, len(col)) == 0
-    assert L.hcspmm_plan_check(ctypes.byref(h), len(rp), len(col)) == capi.EPLAN
-    h.magic = 0
-    assert L.hcspmm_plan_check(ctypes.byref(h), len(rp) - 1, len(col)) == capi.EPLAN
+    N, E = len(rp) - 1, len(col)
+    assert L.hcspmm_plan_check(ctypes.byref(h), N, E, len(plan)) == 0
+    assert L.hcspmm_plan_check(ctypes.byref(h), N, E, 0) == 0                      # buffer length unknown: not checked
+    assert L.hcspmm_plan_check(ctypes.byref(h), N, E, len(plan) - 1) == capi.EPLAN  # blob longer than its buffer
+    assert L.hcspmm_plan_check(ctypes.byref(h), N + 1, E, 0) == capi.EPLAN
+    for field, bad in (("magic", 0), ("n_tiny", h.n_tasks + 1), ("off_fixups", h.total_words + 4),
+                       ("off_sparse_windows", h.total_words), ("n_sparse_windows", h.n_sparse_windows + 1),
+                       ("off_dense_index", h.off_tasks), ("nnz_sparse", h.nnz_sparse + 1), ("num_columns", 0),
+                       ("total_words", h.off_sparse_windows)):
+        keep = getattr(h, field)
+        setattr(h, field, bad)
+        assert L.hcspmm_plan_check(ctypes.byref(h), N, E, 0) == capi.EPLAN, field
+        setattr(h, field, keep)
+    keep = h.n_len_gt[2]
+    h.n_len_gt[2] = h.n_tasks - h.n_tiny + 1  # a wide-task prefix beyond the non-tiny tasks
+    assert L.hcspmm_plan_check(ctypes.byref(h), N, E, 0) == capi.EPLAN
+    h.n_len_gt[2] = keep
+    assert L.hcspmm_plan_check(ctypes.byref(h), N, E, 0) == 0
+
+
+def test_column_ids_are_range_checked_on_the_host(capi):
+    """A column id outside [0, num_columns) is refused by preprocess and by plan_build (HCSPMM_EINVAL) instead of
+    becoming an out-of-bounds gather on the GPU; num_columns > num_nodes admits the row block of a sharded graph."""
+    L = capi.lib()
+    rp, col = graphs.powerlaw_graph(300, 2000, seed=3)
+    N, E = len(rp) - 1, len(col)
+    W = (N + 15) // 16
+    bp, ht, e2c, e2r = (np.zeros(W, np.int32), np.zeros(W, np.int32), np.zeros(E, np.int32), np.zeros(E, np.int32))
+
+    def pre(c, M, threads=1):
+        return L.hcspmm_preprocess_host(rp.ctypes.data, c.ctypes.data, N, E, M, 0, threads, bp.ctypes.data, e2c.ctypes.data,
+                                        e2r.ctypes.data, ht.ctypes.data)
+    assert pre(col, N) == 0 and pre(col, 0) == 0
+    for bad_value in (N, -1, 2 ** 31 - 1):
+        bad = col.copy()
+        bad[E // 2] = bad_value
+        assert pre(bad, N) == capi.EINVAL
+    wide = col.copy()
+    wide[-1] = 4 * N - 1           # legal for a row block whose columns span 4*N rows of the gathered matrix
+    order = np.argsort(wide[rp[N - 1]:rp[N]], kind="stable")
+    wide[rp[N - 1]:rp[N]] = wide[rp[N - 1]:rp[N]][order]
+    assert pre(wide, N) == capi.EINVAL and pre(wide, 4 * N) == 0
+    with pytest.raises(RuntimeError, match="invalid argument"):
+        hcspmm.preprocess(_t(wide), _t(rp), N, E, W)
+    outs = hcspmm.preprocess(_t(wide), _t(rp), N, E, W, num_columns=4 * N)
+    h = hcspmm.plan_header(outs[4])
+    assert h.num_columns == 4 * N and h.n_sparse_windows + h.n_dense == W
+    # plan_build on its own checks too (a plan may be built for a caller's classification)
+    words = ctypes.c_int64(0)
+    assert pre(col, N) == 0
+    assert L.hcspmm_plan_words(rp.ctypes.data, N, E, bp.ctypes.data, ht.ctypes.data, None, ctypes.byref(words)) == 0
+    plan = np.zeros(words.value, np.int32)
+    bad = col.copy()
+    bad[0] = N + 5
+    assert L.hcspmm_plan_build(rp.ctypes.data, bad.ctypes.data, N, E, N, bp.ctypes.data, e2c.ctypes.data, ht.ctypes.data, None,
+                               plan.ctypes.data, words.value) == capi.EINVAL
+    assert L.hcspmm_plan_build(rp.ctypes.data, col.ctypes.data, N, E, N, bp.ctypes.data, e2c.ctypes.data, ht.ctypes.data, None,
+                               plan.ctypes.data, words.value) == 0
+
+
+def test_graph_fingerprint_tells_graphs_of_equal_size_apart(capi):
+    L = capi.lib()
+    rp, col = graphs.powerlaw_graph(400, 3000, seed=5)
+    N, E = len(rp) - 1, len(col)
+
+    def fp(r, c):
+        out = ctypes.c_uint64(0)
+        assert L.hcspmm_graph_fingerprint_host(r.ctypes.data, c.ctypes.data, len(r) - 1, len(c), ctypes.byref(out)) == 0
+        return out.value
+    base = fp(rp, col)
+    assert base == fp(rp.copy(), col.copy())
+    plan = _pre(rp, col)[4].numpy()
+    assert Header.from_buffer_copy(plan[:Header.WORDS].tobytes()).fingerprint == base
+    swapped = col.copy()          # same N, E, same multiset of ids: two entries exchanged
+    i, j = rp[10], rp[200]
+    swapped[i], swapped[j] = col[j], col[i]
+    assert fp(rp, swapped) != base
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(1)).to(torch.int32)
+    rp2, col2 = hcspmm.apply_permutation(_t(rp), _t(col), perm)  # a relabelled graph keeps N and E
+    assert fp(rp2.numpy(), col2.numpy()) != base
+    # threaded pass (> 2^18 elements) == single-threaded definition
+    rp3, col3 = graphs.powerlaw_graph(60000, 400000, seed=5)
+    want = capi_fingerprint_reference(rp3, col3)
+    assert fp(rp3, col3) == want
+
+
+def capi_fingerprint_reference(rp, col):
+    """The definition in csrc/fingerprint.h, restated with numpy (uint64 wrap-around arithmetic)."""
+    M = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+    def mix(x):
+        x = (x + np.uint64(0x9e3779b97f4a7c15)) & M
+        x = ((x ^ (x >> np.uint64(30))) * np.uint64(0xbf58476d1ce4e5b9)) & M
+        x = ((x ^ (x >> np.uint64(27))) * np.uint64(0x94d049bb133111eb)) & M
+        return x ^ (x >> np.uint64(31))
+    with np.errstate(over="ignore"):
+        N, E = len(rp) - 1, len(col)
+        r = np.arange(N + 1, dtype=np.uint64)
+        e = np.arange(E, dtype=np.uint64)
+        t_rp = mix(~((r << np.uint64(32)) | rp.astype(np.uint32).astype(np.uint64)))
+        t_col = mix((e << np.uint64(32)) | col.astype(np.uint32).astype(np.uint64))
+        seed = mix(np.array([(N << 32) ^ E ^ 0x4843535000000000], dtype=np.uint64))
+        return int((t_rp.sum(dtype=np.uint64) + t_col.sum(dtype=np.uint64) + seed[0]) & M)
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "loi_*.npz"))))

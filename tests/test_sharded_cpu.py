@@ -57,7 +57,7 @@ def _worker(rank, world, port, seed, D, out_dir):
         # preprocess runs per shard on local windows with (remapped) global columns: host side only
         import hcspmm
         outs = hcspmm.preprocess(torch.from_numpy(g.column_index), torch.from_numpy(g.row_pointers), g.n_local,
-                                 len(g.column_index), (g.n_local + 15) // 16)
+                                 len(g.column_index), (g.n_local + 15) // 16, num_columns=g.world_size * g.pad_rows)
         want_pre = oracle.preprocess(g.row_pointers, g.column_index)
         ok = ok and all(np.array_equal(a, b.numpy()) for a, b in zip(want_pre, outs[:4]))
         np.save(os.path.join(out_dir, "ok_%d.npy" % rank), np.array([ok, g.r0, g.r1]))
@@ -120,7 +120,8 @@ def _gpu_worker(rank, world, port, out_dir):
         X = np.random.default_rng(3).standard_normal((N, D)).astype(np.float32)
         g = ShardedGraph(rp, col, partition_rows(rp, world), rank)
         rp_d, col_d = torch.from_numpy(g.row_pointers).to(dev), torch.from_numpy(g.column_index).to(dev)
-        outs = hcspmm.preprocess(col_d, rp_d, g.n_local, len(g.column_index), (g.n_local + 15) // 16)
+        outs = hcspmm.preprocess(col_d, rp_d, g.n_local, len(g.column_index), (g.n_local + 15) // 16,
+                                 num_columns=g.world_size * g.pad_rows)
         op = ShardedSpMM(g, lambda Xf: hcspmm.forward_rect(Xf, rp_d, col_d, *outs)[0],
                          local_spmm_into=lambda Xf, Zv: hcspmm.forward_into(Xf, Zv, rp_d, col_d, *outs), n_panels=2)
         Z = op(torch.from_numpy(X[g.r0:g.r1]).to(dev)).cpu().numpy()

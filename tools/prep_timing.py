@@ -17,14 +17,14 @@ for name,(rp,col) in (('reddit',graphs.powerlaw_graph(233000,11600000,seed=3)),(
         t2=time.perf_counter()
         for th in (0,16,32,64):
             ta=time.perf_counter()
-            L.hcspmm_preprocess_host(rp_h.data_ptr(),col_h.data_ptr(),N,E,0,th,bp.data_ptr(),e2c.data_ptr(),e2r.data_ptr(),ht.data_ptr())
+            L.hcspmm_preprocess_host(rp_h.data_ptr(),col_h.data_ptr(),N,E,N,0,th,bp.data_ptr(),e2c.data_ptr(),e2r.data_ptr(),ht.data_ptr())
             tb=time.perf_counter()
             if rep: print(name,'preprocess_host threads',th,'%.1f ms'%((tb-ta)*1e3))
         t3=time.perf_counter()
         words=ctypes.c_int64(0); L.hcspmm_plan_words(rp_h.data_ptr(),N,E,bp.data_ptr(),ht.data_ptr(),None,ctypes.byref(words))
         plan=torch.zeros(words.value,dtype=torch.int32)
         t4=time.perf_counter()
-        L.hcspmm_plan_build(rp_h.data_ptr(),col_h.data_ptr(),N,E,bp.data_ptr(),e2c.data_ptr(),ht.data_ptr(),None,plan.data_ptr(),plan.numel())
+        L.hcspmm_plan_build(rp_h.data_ptr(),col_h.data_ptr(),N,E,N,bp.data_ptr(),e2c.data_ptr(),ht.data_ptr(),None,plan.data_ptr(),plan.numel())
         t5=time.perf_counter()
         outs=[t.to(dev) for t in (bp,e2c,e2r,ht,plan)]; torch.cuda.synchronize(); t6=time.perf_counter()
         if rep: print(name,'D2H %.1f alloc %.1f planwords+alloc %.1f plan_build %.1f H2D %.1f ms (E=%d, plan %d words)'%((t1-t0)*1e3,(t2-t1)*1e3,(t4-t3)*1e3,(t5-t4)*1e3,(t6-t5)*1e3,E,words.value))

@@ -56,7 +56,7 @@ inline int64_t align4(int64_t x) { return (x + 3) & ~int64_t(3); }
 struct Layout {
   int64_t n_tasks = 0, n_dense = 0, n_compact = 0, n_compact2 = 0, n_split_rows = 0, n_partials = 0;
   int64_t dense_pack_words = 0;
-  int64_t nnz_sparse = 0, nnz_dense = 0;
+  int64_t nnz_sparse = 0, nnz_dense = 0, dense_k_sum = 0;
   int32_t max_dense_k = 0;
   int64_t n_sparse_windows = 0;
   int64_t off_tasks = 0, off_dense_index = 0, off_dense_pack = 0, off_compact2 = 0, off_compact = 0, off_fixups = 0,
@@ -78,6 +78,7 @@ int compute_layout(const int32_t* rowptr, int64_t N, const int32_t* bp, const in
       else if (K <= HCSPMM_COMPACT2_K) L.n_compact2++;
       else L.dense_pack_words += K + (K / 4) * 2;  // U[K] + one 64-bit mask per 4 columns
       L.nnz_dense += nnz;
+      L.dense_k_sum += K;
       L.max_dense_k = std::max<int32_t>(L.max_dense_k, (int32_t)K);
     } else {
       L.n_sparse_windows++;
@@ -407,6 +408,7 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
   h.off_sparse_windows = (int32_t)L.off_sparse_windows;
   h.fingerprint_lo = (uint32_t)(fingerprint & 0xffffffffull);
   h.fingerprint_hi = (uint32_t)(fingerprint >> 32);
+  h.dense_k_sum = (int32_t)std::min<int64_t>(L.dense_k_sum, INT32_MAX);
   static_assert(sizeof(hcspmm_plan_header) == HCSPMM_PLAN_HEADER_WORDS * 4, "header size");
   std::memcpy(plan, &h, sizeof(h));
   return HCSPMM_OK;

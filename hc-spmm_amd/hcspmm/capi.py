@@ -27,7 +27,7 @@ class Header(ctypes.Structure):
                                                                                   ("off_dense_compact2", ctypes.c_int32), ("num_columns", ctypes.c_int32),
                                                                                   ("n_sparse_windows", ctypes.c_int32), ("off_sparse_windows", ctypes.c_int32),
                                                                                   ("fingerprint_lo", ctypes.c_uint32), ("fingerprint_hi", ctypes.c_uint32),
-                                                                                  ("reserved", ctypes.c_int32 * 29)]
+                                                                                  ("dense_k_sum", ctypes.c_int32), ("reserved", ctypes.c_int32 * 28)]
 
     @property
     def fingerprint(self):

@@ -136,6 +136,91 @@ def planted_dense_graph_fast(num_nodes, seed=0, dense_fraction=0.7, k_cols=16, f
     return _to_csr(rows, cols, N)
 
 
+def _capped_powerlaw_cdf(n, cap_prob, exponent=2.1):
+    """CDF of endpoint weights w_i ~ (i+1)^(-1/(exponent-1)) with every probability capped at cap_prob."""
+    alpha = 1.0 / (exponent - 1.0)
+    w = (np.arange(n, dtype=np.float64) + 1.0) ** (-alpha)
+    w /= w.sum()
+    for _ in range(8):
+        w = np.minimum(w, cap_prob)
+        w /= w.sum()
+    c = np.cumsum(w)
+    c[-1] = 1.0
+    return c
+
+
+def powerlaw_block(n_rows, n_cols, n_entries, seed=0, rank=0, rows=None):
+    """Row block of a power-law graph: `n_rows` local rows, column ids global in [0, n_cols), ~n_entries stored
+    entries.  Row degrees follow a (shuffled) local power law, columns a global one whose relabelling depends on
+    `seed` only -- so every rank of a sharded job agrees on which columns are popular -- while the draws depend on
+    (seed, rank): cheap to generate per rank, no exchange.  `rows` (optional, ascending local ids): put the
+    entries on these rows only.  Returns (row_pointers[n_rows+1], column_index) int32."""
+    rng = np.random.default_rng(seed + 1000 * rank)
+    n_draw_rows = int(n_rows if rows is None else len(rows))
+    if n_draw_rows == 0 or n_entries <= 0:
+        return np.zeros(n_rows + 1, np.int32), np.zeros(0, np.int32)
+    cap = 0.02 * max(n_draw_rows, 1) / max(n_entries, 1)
+    rcdf = _capped_powerlaw_cdf(n_draw_rows, cap)
+    ccdf = _capped_powerlaw_cdf(n_cols, cap)
+    rperm = rng.permutation(n_draw_rows)
+    cperm = np.random.default_rng(seed).permutation(n_cols)  # same column relabelling on every rank
+    draw = int(n_entries * 1.12)
+    r = rperm[np.searchsorted(rcdf, rng.random(draw))].astype(np.int64)
+    if rows is not None:
+        r = np.asarray(rows, dtype=np.int64)[r]
+    c = cperm[np.searchsorted(ccdf, rng.random(draw))].astype(np.int64)
+    key = np.unique(r * n_cols + c)
+    if key.shape[0] > n_entries:
+        key = np.sort(rng.choice(key, int(n_entries), replace=False))
+    rr, cc = key // n_cols, key % n_cols
+    rp = np.zeros(n_rows + 1, np.int64)
+    np.add.at(rp, rr + 1, 1)
+    return np.cumsum(rp).astype(np.int32), cc.astype(np.int32)
+
+
+def planted_powerlaw_block(n_rows, n_cols, n_entries, seed=0, rank=0, dense_fraction=0.7, k_range=(8, 24), fill=0.7,
+                           chunk_windows=1 << 16):
+    """BASELINE config 5's mix as SURVEY.md 8(d) defines it ("planted 16-row groups sharing <= 24 columns so that
+    the classifier sends a large fraction of windows to the dense path"), as a row block: n_rows local rows,
+    column ids global in [0, n_cols), ~n_entries stored entries (n_cols == n_rows: the whole square graph).
+
+    A `dense_fraction` of the 16-row windows are planted groups -- the layout a LOI reorder produces: K in k_range
+    shared columns (uniform over ALL n_cols, i.e. no locality in X), each row linked to each of them with
+    probability `fill`.  With K <= 24 and fill >= 0.25 the reference's classifier (rule 0: 0.1985*(K-1) -
+    6.578*density - 3.149 <= 0) sends every such window to the dense-tile path.  The other windows are
+    unstructured power-law rows (sparse-row path) holding the rest of the entries.  Duplicate-free, columns
+    ascending per row; generated in chunks so the 16 M-node full size stays within a few GB of host memory."""
+    rng = np.random.default_rng(seed + 7919 * rank + 1)
+    N, M = int(n_rows), int(n_cols)
+    W = (N + 15) // 16
+    kmax = int(k_range[1])
+    is_dense = rng.random(W) < dense_fraction
+    dw = np.nonzero(is_dense)[0]
+    r_parts, c_parts = [], []
+    n_planted = 0
+    for a in range(0, dw.shape[0], chunk_windows):
+        wch = dw[a:a + chunk_windows]
+        K = rng.integers(k_range[0], kmax + 1, wch.shape[0])
+        cset = rng.integers(0, M, (wch.shape[0], kmax), dtype=np.int64)
+        m = (rng.random((wch.shape[0], 16, kmax), dtype=np.float32) < fill) & (np.arange(kmax)[None, None, :] < K[:, None, None])
+        wi, ri, ki = np.nonzero(m)
+        rr = wch[wi] * 16 + ri
+        ok = rr < N
+        r_parts.append(rr[ok].astype(np.int64))
+        c_parts.append(cset[wi, ki][ok])
+        n_planted += int(ok.sum())
+    srows = np.nonzero(~np.repeat(is_dense, 16)[:N])[0]
+    rp_s, col_s = powerlaw_block(N, M, max(int(n_entries) - n_planted, 0), seed=seed, rank=rank, rows=srows)
+    r_parts.append(np.repeat(np.arange(N, dtype=np.int64), np.diff(rp_s)))
+    c_parts.append(col_s.astype(np.int64))
+    key = np.unique(np.concatenate(r_parts) * M + np.concatenate(c_parts))
+    del r_parts, c_parts
+    rr, cc = key // M, key % M
+    rp = np.zeros(N + 1, np.int64)
+    np.add.at(rp, rr + 1, 1)
+    return np.cumsum(rp).astype(np.int32), cc.astype(np.int32)
+
+
 def molecule_graph(num_nodes, seed=0, size_range=(10, 46), heavy_fraction=0.45):
     """Collection of small molecule-like components laid out one after another (the shape of the
     TU-collection datasets in the paper's Table II -- YeastH, OVCAR-8H, ...: millions of nodes, average

@@ -7,7 +7,17 @@ blocks (RCCL over xGMI when the backend is "nccl"); no reduction is needed becau
 row-sharded.  Blocks are padded to a common height so the gather is a single
 all_gather_into_tensor; global column ids are remapped once, on the host, to rows of the padded
 gathered matrix.  The local product is whatever callable the caller supplies -- the HIP operator
-in production (hcspmm.forward); CPU tests inject the oracle -- so this module contains no compute.
+in production (hcspmm.forward_rect / forward_into); CPU tests inject the oracle -- so this module
+contains no compute.
+
+Data layout (what makes a step allocation- and copy-free): features live PANEL-MAJOR on every rank --
+X_pm[n_panels][pad_rows][w], w = D / n_panels columns per panel (one 128-byte line per row for w = 32
+fp32) -- and so does the result, Z_pm[n_panels][n_local][w].  Panel p of X is then a contiguous
+[pad_rows, w] matrix that all_gather_into_tensor takes as it is (no .contiguous() copy), the gathered
+panel is a contiguous [P*pad_rows, w] matrix -- the layout the gather kernel likes best -- and the
+product of panel p is written straight into Z_pm[p].  Z_pm has the layout of X_pm, so the output of
+one aggregation is the input of the next without a transpose.  All buffers (X_pm, the P-times-larger
+gather targets, Z_pm, the split-row workspace) are allocated once by bind() and reused by every step.
 """
 import numpy as np
 import torch
@@ -47,6 +57,11 @@ class ShardedGraph:
         self.row_pointers = (rp[self.r0:self.r1 + 1] - e0).astype(np.int32)
         self.column_index = self.remap_columns(col[e0:e1]).astype(np.int32)
 
+    @property
+    def num_columns(self):
+        """Rows of the padded gathered matrix = the column space of the local block (preprocess num_columns=)."""
+        return self.world_size * self.pad_rows
+
     def remap_columns(self, cols):
         """global vertex id -> row of the padded gathered matrix (owner * pad_rows + local index)."""
         starts = np.array([r[0] for r in self.ranges], dtype=np.int64)
@@ -68,69 +83,93 @@ class ShardedGraph:
 
 
 class ShardedSpMM:
-    """Z_local = A[rows_p, :] @ all_gather(X_local).
+    """Z_local = A[rows_p, :] @ all_gather(X_local), panel by panel, with persistent buffers.
 
-    local_spmm(X_full[P*pad_rows, D]) -> Z_local[n_local, D] is the local operator.
-    With local_spmm_into(X_panel_full[P*pad_rows, w], Z_view[n_local, w]) and n_panels > 1 the feature
-    columns are cut into n_panels panels: every panel's all-gather is enqueued up front
-    (async_op=True, so RCCL runs them back to back on its own stream) and the product of panel k is
-    issued as soon as gather k has landed -- it overlaps gather k+1, which is the longer of the two on
-    xGMI.  Each gathered panel is a contiguous [P*pad_rows, w] matrix, which is
-    also the layout the gather kernel likes best (one cache line per row for w = 32), and each product
-    is written straight into its column slice of Z (strided operator, no concatenation).
+    local_spmm_into(X_panel_full[P*pad_rows, w], Z_view[n_local, w], workspace) is the local operator on one
+    column panel (hcspmm.forward_into in production).  With n_panels > 1 every panel's all-gather is enqueued
+    up front (async_op=True, so RCCL runs them back to back on its own stream) and the product of panel k is
+    issued as soon as gather k has landed -- it overlaps gather k+1, which is the longer of the two on xGMI
+    (DESIGN.md section 6).
+
+    Use:  op.bind(D, dtype, device)            once: allocates X_pm, the gather targets, Z_pm, the workspace
+          op.features()[...] = ...             fill the panel-major local features (or op.load_features(X))
+          Z_pm = op.step()                     one SpMM: gathers + products; returns the persistent Z_pm
+    forward(X_local) is the row-major convenience form (one strided copy in, one out); the step itself
+    allocates and copies nothing.
     """
 
-    def __init__(self, graph, local_spmm, group=None, local_spmm_into=None, n_panels=1):
+    def __init__(self, graph, local_spmm_into, group=None, n_panels=1, workspace_bytes=None):
         self.g = graph
-        self.local_spmm = local_spmm
         self.local_spmm_into = local_spmm_into
-        self.n_panels = n_panels if local_spmm_into is not None else 1
+        self.n_panels = max(1, int(n_panels))
         self.group = group
+        self._workspace_bytes = workspace_bytes  # callable(panel_width) -> bytes, or None
+        self.D = None
 
-    def _pad(self, X_local):
+    # ------------------------------------------------------------------ buffers
+    def bind(self, D, dtype, device):
         g = self.g
-        if X_local.shape[0] == g.pad_rows:
-            return X_local
-        pad = torch.zeros((g.pad_rows, X_local.shape[1]), dtype=X_local.dtype, device=X_local.device)
-        pad[:g.n_local] = X_local
-        return pad
+        if D % self.n_panels != 0:
+            raise ValueError("embedding_dim %d is not a multiple of n_panels %d" % (D, self.n_panels))
+        self.D, self.w = int(D), int(D) // self.n_panels
+        self.dtype, self.device = dtype, torch.device(device)
+        kw = dict(dtype=dtype, device=self.device)
+        self.X_pm = torch.zeros((self.n_panels, g.pad_rows, self.w), **kw)  # padding rows stay zero
+        self.Z_pm = torch.empty((self.n_panels, g.n_local, self.w), **kw)
+        # world 1: the product reads X_pm itself
+        self.gathered = [torch.empty((g.world_size * g.pad_rows, self.w), **kw) for _ in range(self.n_panels)] \
+            if g.world_size > 1 else None
+        nbytes = int(self._workspace_bytes(self.w)) if self._workspace_bytes is not None else 0
+        self.workspace = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=self.device) if nbytes else None
+        self._host_stage = None
+        return self
 
-    def _all_gather(self, full, part, async_op=False):
+    def features(self):
+        """Panel-major view [n_panels, n_local, w] of this rank's features, to be filled in place."""
+        return self.X_pm[:, :self.g.n_local, :]
+
+    def load_features(self, X_local):
+        """Row-major [n_local, D] -> the panel-major buffer (one strided device copy, no allocation)."""
+        self.features().copy_(X_local.reshape(self.g.n_local, self.n_panels, self.w).permute(1, 0, 2))
+
+    def buffers(self):
+        """Every tensor a step touches, for allocation-freeness checks."""
+        return [self.X_pm, self.Z_pm] + (self.gathered or []) + ([self.workspace] if self.workspace is not None else [])
+
+    # ------------------------------------------------------------------ one SpMM
+    def _all_gather(self, full, part, async_op):
         if part.is_cuda and dist.get_backend(self.group) != "nccl":
-            # rehearsal mode (e.g. several ranks sharing one GPU over gloo): stage through the host
-            host = torch.empty(full.shape, dtype=full.dtype)
-            dist.all_gather_into_tensor(host, part.cpu(), group=self.group)
-            full.copy_(host)
+            # rehearsal mode (several ranks sharing one GPU over gloo): stage through the host
+            if self._host_stage is None:
+                self._host_stage = (torch.empty(full.shape, dtype=full.dtype), torch.empty(part.shape, dtype=part.dtype))
+            host_full, host_part = self._host_stage
+            host_part.copy_(part)
+            dist.all_gather_into_tensor(host_full, host_part, group=self.group)
+            full.copy_(host_full)
             return None
         return dist.all_gather_into_tensor(full, part, group=self.group, async_op=async_op)
 
-    def gather(self, X_local):
+    def step(self):
         g = self.g
         if g.world_size == 1:
-            return X_local
-        X_local = self._pad(X_local).contiguous()
-        full = torch.empty((g.world_size * g.pad_rows, X_local.shape[1]), dtype=X_local.dtype, device=X_local.device)
-        self._all_gather(full, X_local)
-        return full
-
-    def forward(self, X_local):
-        g = self.g
-        D = X_local.shape[1]
-        if g.world_size == 1 or self.n_panels <= 1 or D % self.n_panels != 0:
-            return self.local_spmm(self.gather(X_local))
-        w = D // self.n_panels
-        Xp = self._pad(X_local)
-        fulls, works = [], []
-        for p in range(self.n_panels):
-            part = Xp[:, p * w:(p + 1) * w].contiguous()
-            full = torch.empty((g.world_size * g.pad_rows, w), dtype=Xp.dtype, device=Xp.device)
-            works.append(self._all_gather(full, part, async_op=True))
-            fulls.append(full)
-        Z = torch.empty((g.n_local, D), dtype=Xp.dtype, device=Xp.device)
+            for p in range(self.n_panels):
+                self.local_spmm_into(self.X_pm[p], self.Z_pm[p], self.workspace)
+            return self.Z_pm
+        works = [self._all_gather(self.gathered[p], self.X_pm[p], async_op=True) for p in range(self.n_panels)]
         for p in range(self.n_panels):
             if works[p] is not None:
                 works[p].wait()  # the current stream waits for gather p; gathers p+1.. keep running
-            self.local_spmm_into(fulls[p], Z[:, p * w:(p + 1) * w])
-        return Z
+            self.local_spmm_into(self.gathered[p], self.Z_pm[p], self.workspace)
+        return self.Z_pm
+
+    def forward(self, X_local):
+        """Row-major convenience form: [n_local, D] -> [n_local, D] (a new tensor when n_panels > 1)."""
+        if self.D is None or self.D != X_local.shape[1] or self.dtype != X_local.dtype or self.device != X_local.device:
+            self.bind(X_local.shape[1], X_local.dtype, X_local.device)
+        self.load_features(X_local)
+        Z_pm = self.step()
+        if self.n_panels == 1:
+            return Z_pm[0]
+        return Z_pm.permute(1, 0, 2).reshape(self.g.n_local, self.D)
 
     __call__ = forward

@@ -478,7 +478,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     d["uniq_dense"] = h.uniq_dense; d["split_threshold"] = h.split_threshold; d["segment_len"] = h.segment_len;
     d["max_dense_k"] = h.max_dense_k; d["n_tiny"] = h.n_tiny; d["n_dense_compact"] = h.n_dense_compact;
     d["n_dense_compact2"] = h.n_dense_compact2; d["num_columns"] = h.num_columns;
-    d["n_sparse_windows"] = h.n_sparse_windows; d["num_nodes"] = h.num_nodes; d["num_edges"] = h.num_edges;
+    d["n_sparse_windows"] = h.n_sparse_windows; d["dense_k_sum"] = h.dense_k_sum; d["num_nodes"] = h.num_nodes; d["num_edges"] = h.num_edges;
     d["fingerprint"] = ((uint64_t)h.fingerprint_hi << 32) | h.fingerprint_lo;
     return d;
   }, "fields of the launch plan carried in row_nzr ({} for the reference's [0] placeholder)");

@@ -135,7 +135,9 @@ typedef struct hcspmm_plan_header {
                                hcspmm_forward_fused still has to multiply by the weights */
   uint32_t fingerprint_lo;  /* hcspmm_graph_fingerprint_host(row_pointers, column_index) of the graph the plan was */
   uint32_t fingerprint_hi;  /* built from: a plan for another graph with the same N and E is told apart by it */
-  int32_t reserved[29];
+  int32_t dense_k_sum;      /* sum over dense windows of K = 8*blockPartition (padded condensed columns): the
+                               dense-tile path executes exactly 2*16*K*D flop per window */
+  int32_t reserved[28];
 } hcspmm_plan_header;
 
 /* Tunables for the plan; zero-initialise for defaults. */

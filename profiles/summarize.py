@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 CSV output (gpurun_out/prof/<pass>/...) into profiles/<round>/ and refresh
-profiles/traffic.json, which bench.py reads for roofline.traffic.
+profiles/measured.json -- the recorded per-launch figures (fabric traffic, L2 hit rate, MFMA utilisation) that
+bench.py quotes, WITH their source file and the hash of the kernel sources they were measured on, for the sweep
+entries and as the fallback when its own live counter passes are unavailable.
 
   python profiles/summarize.py gpurun_out/prof_round/reddit_d128 profiles/r01 reddit_d128
 
@@ -61,9 +63,18 @@ def main():
             active = m["GRBM_GUI_ACTIVE"] / 8.0
             out["mfma_util_percent"] = 100.0 * m["SQ_VALU_MFMA_BUSY_CYCLES"] / (active * simds)
             out["mfma_flops_per_launch"] = m.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0) * 512.0
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic.json")
+        here = os.path.dirname(os.path.abspath(__file__))
+        sys.path.insert(0, os.path.dirname(here))
+        import bench  # kernel_src_sha(): which sources these numbers belong to
+        tpath = os.path.join(here, "measured.json")
         t = json.load(open(tpath)) if os.path.exists(tpath) else {}
-        t[key] = fetch_b + write_b
+        kern = [v for k, v in out["kernels"].items() if "hybrid" in k]
+        t[key] = {"traffic_bytes": fetch_b + write_b, "fetch_bytes": fetch_b, "write_bytes": write_b,
+                  "l2_hit_rate": out.get("l2_hit_rate"), "mfma_util_percent": out.get("mfma_util_percent"),
+                  "mfma_flops_per_launch": out.get("mfma_flops_per_launch"),
+                  "kernel_ms": (kern[0]["avg_ns"] / 1e6) if kern else None,
+                  "source": os.path.relpath(os.path.join(dst, "%s_summary.json" % key), os.path.dirname(here)),
+                  "kernel_src_sha": bench.kernel_src_sha()}
         json.dump(t, open(tpath, "w"), indent=1, sort_keys=True)
     json.dump(out, open(os.path.join(dst, "%s_summary.json" % key), "w"), indent=1, sort_keys=True)
     print(json.dumps(out, indent=1, sort_keys=True))

@@ -1,0 +1,91 @@
+"""The two Python front-ends over the C ABI of libhcspmm.so, behind one small adapter so that the GPU parity
+matrix runs through both:
+
+  * "ctypes"    -- hc-spmm_amd/hcspmm (ctypes glue; what bench.py uses by default);
+  * "extension" -- the torch extension module `HCSPMM` built from hc-spmm_amd/hybrid_kernel/, i.e. the reference's
+                   own Python-visible boundary (/root/reference/hybrid_kernel/hybrid_all.cpp:500-525) that
+                   GNN_model.py / HC-SpMM_main.py import.
+
+Both forward device pointers to the same entry points; what differs -- and what running the matrix twice covers --
+is the boundary code: plan registry, graph-fingerprint check, workspace handling, dtype dispatch, argument checks.
+"""
+import os
+import sys
+import types
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXT_DIR = os.path.join(ROOT, "hc-spmm_amd", "hybrid_kernel")
+
+_DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+FORWARD_NAMES = ["forward", "forward_more", "forward_fixed32", "forward_fixed64", "backward", "backward_fixed32",
+                 "backward_fixed64"]
+FUSED_NAMES = ["forward_fixed32_fused", "forward_fixed64_fused", "forward_GIN_final_fused", "backward_fixed32_fused",
+               "backward_fixed64_fused", "backward_GIN_final_fused"]
+FINAL_FUSED_NAMES = ["forward_final_fused", "forward_final_fused_64", "backward_final_fused", "backward_final_fused_64"]
+
+
+class CtypesFrontend:
+    name = "ctypes"
+
+    def __init__(self):
+        import hcspmm
+        self.m = hcspmm
+
+    def __getattr__(self, name):  # forward*, backward*, forward_rect, forward_into, ...
+        return getattr(self.m, name)
+
+    def preprocess(self, col_d, rp_d, N, E, W, rule=0, num_columns=None):
+        return self.m.preprocess(col_d, rp_d, N, E, W, rule=rule, num_columns=num_columns)
+
+    def build_plan(self, rp_d, col_d, bp, e2c, ht, split_threshold=0, segment_len=0, num_columns=None):
+        return self.m.build_plan(rp_d, col_d, bp, e2c, ht, split_threshold=split_threshold, segment_len=segment_len,
+                                 num_columns=num_columns)
+
+    def header(self, row_nzr):
+        return self.m.plan_header(row_nzr)
+
+    def wide_threshold(self, row_nzr, D, dtype=torch.float32):
+        return self.m.wide_threshold(row_nzr, D, dtype)
+
+
+class ExtensionFrontend:
+    name = "extension"
+
+    def __init__(self):
+        if EXT_DIR not in sys.path:
+            sys.path.insert(0, EXT_DIR)
+        import HCSPMM  # built in-tree by __graft_entry__.build(); fails loudly if absent
+        self.m = HCSPMM
+
+    def __getattr__(self, name):
+        return getattr(self.m, name)
+
+    def preprocess(self, col_d, rp_d, N, E, W, rule=0, num_columns=None):
+        self.m.set_rule(int(rule))  # the reference's signature has no rule argument: module-level switch
+        try:
+            return self.m.preprocess(col_d, rp_d, N, E, W, -1 if num_columns is None else int(num_columns))
+        finally:
+            self.m.set_rule(0)
+
+    def build_plan(self, rp_d, col_d, bp, e2c, ht, split_threshold=0, segment_len=0, num_columns=None):
+        return self.m.build_plan(rp_d, col_d, bp, e2c, ht, int(split_threshold), int(segment_len),
+                                 -1 if num_columns is None else int(num_columns))
+
+    def header(self, row_nzr):
+        info = self.m.plan_info(row_nzr)
+        return types.SimpleNamespace(**info) if info else None
+
+    def wide_threshold(self, row_nzr, D, dtype=torch.float32):
+        return int(self.m.wide_threshold(row_nzr, int(D), _DT[dtype]))
+
+
+_CACHE = {}
+
+
+def get(name):
+    if name not in _CACHE:
+        _CACHE[name] = {"ctypes": CtypesFrontend, "extension": ExtensionFrontend}[name]()
+    return _CACHE[name]

@@ -1,4 +1,4 @@
-"""Multi-process (gloo, world_size 2, CPU) tests of the row-block shard + all-gather(X) layer.
+"""Multi-process (gloo, world_size 2 / 3 / 4 / 8, CPU) tests of the row-block shard + all-gather(X) layer.
 The local operator injected here is the ORACLE (tests may use it); in production it is the HIP
 operator (hcspmm.forward_rect) -- hcspmm.sharded itself contains no compute."""
 import os
@@ -25,13 +25,14 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, seed, D, out_dir):
+def _worker(rank, world, port, seed, D, n_panels, out_dir):
     for p in (ROOT, os.path.join(ROOT, "hc-spmm_amd")):
         if p not in sys.path:
             sys.path.insert(0, p)
     import oracle
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         rp, col = graphs.powerlaw_graph(1003, 15000, seed=seed)  # N % 16 != 0, unequal blocks
@@ -39,25 +40,33 @@ def _worker(rank, world, port, seed, D, out_dir):
         X = np.random.default_rng(seed).standard_normal((N, D)).astype(np.float32)
         ranges = partition_rows(rp, world)
         g = ShardedGraph(rp, col, ranges, rank)
+        assert len({b - a for a, b in ranges}) > 1  # blocks of unequal height: padding + column remap in play
 
-        def local_spmm(X_full):
-            return torch.from_numpy(oracle.spmm_f32(g.row_pointers, g.column_index, X_full.numpy()))
-
-        op = ShardedSpMM(g, local_spmm)
-        Z_local = op(torch.from_numpy(X[g.r0:g.r1]))
-        want = oracle.spmm_f32(rp, col, X)[g.r0:g.r1]
-        ok = np.array_equal(Z_local.numpy(), want)
-
-        # pipelined form: column panels gathered asynchronously, each multiplied into its slice of Z
-        def local_spmm_into(X_panel_full, Z_view):
+        def local_spmm_into(X_panel_full, Z_view, workspace):
             Z_view.copy_(torch.from_numpy(oracle.spmm_f32(g.row_pointers, g.column_index, X_panel_full.numpy())))
 
-        op2 = ShardedSpMM(g, local_spmm, local_spmm_into=local_spmm_into, n_panels=D // 4)
-        ok = ok and np.array_equal(op2(torch.from_numpy(X[g.r0:g.r1])).numpy(), want)
+        want = oracle.spmm_f32(rp, col, X)[g.r0:g.r1]
+        ok = True
+        for panels in sorted({1, n_panels}):
+            op = ShardedSpMM(g, local_spmm_into, n_panels=panels)
+            Z_local = op(torch.from_numpy(X[g.r0:g.r1]))
+            ok = ok and np.array_equal(Z_local.numpy(), want)
+            # a second and third step reuse every buffer: same storage, nothing new allocated by step()
+            ptrs = [t.data_ptr() for t in op.buffers()]
+            X2 = 2.0 * X[g.r0:g.r1]
+            op.load_features(torch.from_numpy(X2))
+            for _ in range(2):
+                Z_pm = op.step()
+                ok = ok and Z_pm.data_ptr() == op.Z_pm.data_ptr()
+            ok = ok and ptrs == [t.data_ptr() for t in op.buffers()]
+            ok = ok and np.array_equal(Z_pm.permute(1, 0, 2).reshape(g.n_local, D).numpy(), 2.0 * want)
+            # the result is panel-major like the features: it can be fed back without a transpose
+            op.features().copy_(Z_pm)
+            ok = ok and torch.equal(op.features(), op.Z_pm)
         # preprocess runs per shard on local windows with (remapped) global columns: host side only
         import hcspmm
         outs = hcspmm.preprocess(torch.from_numpy(g.column_index), torch.from_numpy(g.row_pointers), g.n_local,
-                                 len(g.column_index), (g.n_local + 15) // 16, num_columns=g.world_size * g.pad_rows)
+                                 len(g.column_index), (g.n_local + 15) // 16, num_columns=g.num_columns)
         want_pre = oracle.preprocess(g.row_pointers, g.column_index)
         ok = ok and all(np.array_equal(a, b.numpy()) for a, b in zip(want_pre, outs[:4]))
         np.save(os.path.join(out_dir, "ok_%d.npy" % rank), np.array([ok, g.r0, g.r1]))
@@ -89,10 +98,10 @@ def test_column_remap_round_trip():
     assert np.array_equal(full[g.column_index, 0], X[col[e0:e1], 0])
 
 
-@pytest.mark.parametrize("world,D", [(2, 8), (2, 32), (3, 16)])
-def test_sharded_spmm_gloo(tmp_path, world, D):
+@pytest.mark.parametrize("world,D,n_panels", [(2, 8, 2), (2, 32, 8), (3, 16, 4), (4, 32, 4), (8, 24, 3)])
+def test_sharded_spmm_gloo(tmp_path, world, D, n_panels):
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, 7, D, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, 7, D, n_panels, str(tmp_path)), nprocs=world, join=True)
     covered = []
     for r in range(world):
         ok, r0, r1 = np.load(tmp_path / ("ok_%d.npy" % r))
@@ -121,10 +130,20 @@ def _gpu_worker(rank, world, port, out_dir):
         g = ShardedGraph(rp, col, partition_rows(rp, world), rank)
         rp_d, col_d = torch.from_numpy(g.row_pointers).to(dev), torch.from_numpy(g.column_index).to(dev)
         outs = hcspmm.preprocess(col_d, rp_d, g.n_local, len(g.column_index), (g.n_local + 15) // 16,
-                                 num_columns=g.world_size * g.pad_rows)
-        op = ShardedSpMM(g, lambda Xf: hcspmm.forward_rect(Xf, rp_d, col_d, *outs)[0],
-                         local_spmm_into=lambda Xf, Zv: hcspmm.forward_into(Xf, Zv, rp_d, col_d, *outs), n_panels=2)
-        Z = op(torch.from_numpy(X[g.r0:g.r1]).to(dev)).cpu().numpy()
+                                 num_columns=g.num_columns)
+        op = ShardedSpMM(g, lambda Xf, Zv, ws: hcspmm.forward_into(Xf, Zv, rp_d, col_d, *outs, workspace=ws), n_panels=2,
+                         workspace_bytes=lambda w: hcspmm.workspace_bytes(outs[4], w))
+        Xd = torch.from_numpy(X[g.r0:g.r1]).to(dev)
+        Z = op(Xd).cpu().numpy()
+        # steady state: a step allocates nothing on the device (persistent gather targets, Z, workspace)
+        assert hcspmm.plan_header(outs[4]).n_split_rows > 0 and op.workspace is not None
+        torch.cuda.synchronize()
+        before = torch.cuda.memory_stats(dev)["allocation.all.allocated"]
+        for _ in range(3):
+            op.step()
+        torch.cuda.synchronize()
+        assert torch.cuda.memory_stats(dev)["allocation.all.allocated"] == before, "step() allocated device memory"
+        assert np.array_equal(op.Z_pm.permute(1, 0, 2).reshape(g.n_local, D).cpu().numpy(), Z)
         e0, e1 = rp[g.r0], rp[g.r1]
         ok, ratio = oracle.check_spmm(Z, (rp[g.r0:g.r1 + 1] - e0).astype(np.int32), col[e0:e1], X)
         np.save(os.path.join(out_dir, "gpu_ok_%d.npy" % rank), np.array([ok, ratio]))
@@ -139,4 +158,58 @@ def test_sharded_spmm_two_ranks_on_one_gpu(tmp_path):
     mp.spawn(_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     for r in range(2):
         ok, ratio = np.load(tmp_path / ("gpu_ok_%d.npy" % r))
+        assert ok == 1, ratio
+
+
+def _nccl_worker(rank, world, port, out_dir):
+    """One rank per GPU over RCCL (backend "nccl"): the configuration bench.py --gpus N runs."""
+    for p in (ROOT, os.path.join(ROOT, "hc-spmm_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import hcspmm
+    import oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        rp, col = graphs.powerlaw_graph(20011, 400000, seed=21, max_degree_frac=0.2)
+        N, D = len(rp) - 1, 128
+        X = np.random.default_rng(5).standard_normal((N, D)).astype(np.float32)
+        g = ShardedGraph(rp, col, partition_rows(rp, world), rank)
+        rp_d, col_d = torch.from_numpy(g.row_pointers).to(dev), torch.from_numpy(g.column_index).to(dev)
+        outs = hcspmm.preprocess(col_d, rp_d, g.n_local, len(g.column_index), (g.n_local + 15) // 16, num_columns=g.num_columns)
+        op = ShardedSpMM(g, lambda Xf, Zv, ws: hcspmm.forward_into(Xf, Zv, rp_d, col_d, *outs, workspace=ws), n_panels=4,
+                         workspace_bytes=lambda w: hcspmm.workspace_bytes(outs[4], w))
+        Z = op(torch.from_numpy(X[g.r0:g.r1]).to(dev))
+        for _ in range(3):  # steady state: the gathers of step k+1 must wait for the products of step k
+            op.step()
+        torch.cuda.synchronize()
+        ok = torch.equal(op.Z_pm.permute(1, 0, 2).reshape(g.n_local, D), Z)
+        # against the single-GPU product of the same row block over the full (padded, gathered) X
+        full = torch.zeros(g.num_columns, D, device=dev)
+        for q, (a, b) in enumerate(g.ranges):
+            full[q * g.pad_rows:q * g.pad_rows + (b - a)] = torch.from_numpy(X[a:b]).to(dev)
+        ok = ok and torch.equal(hcspmm.forward_rect(full, rp_d, col_d, *outs)[0], Z)
+        e0, e1 = rp[g.r0], rp[g.r1]
+        ok2, ratio = oracle.check_spmm(Z.cpu().numpy(), (rp[g.r0:g.r1 + 1] - e0).astype(np.int32), col[e0:e1], X)
+        np.save(os.path.join(out_dir, "nccl_ok_%d.npy" % rank), np.array([ok and ok2, ratio]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_spmm_nccl_one_rank_per_gpu(tmp_path):
+    """Runs only where more than one GPU is visible (the builder's box has one; the driver's scaling node has 8):
+    until it has run there, the RCCL path -- gather/product ordering across streams included -- is UNVERIFIED."""
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("needs >= 2 visible GPUs (RCCL path; unverified on a one-GPU box)")
+    world = min(n, 4)
+    port = _free_port()
+    mp.spawn(_nccl_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        ok, ratio = np.load(tmp_path / ("nccl_ok_%d.npy" % r))
         assert ok == 1, ratio

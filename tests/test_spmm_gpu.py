@@ -1,6 +1,7 @@
 """GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI of
-libhcspmm.so (via the hcspmm host glue, which only forwards device pointers), against the CPU
-oracle on the same seeded inputs.
+libhcspmm.so, against the CPU oracle on the same seeded inputs.  The matrix runs through BOTH Python
+front-ends of that ABI (tests/frontends.py): the ctypes glue `hcspmm` and the torch extension module
+`HCSPMM` -- the reference's own boundary (hybrid_all.cpp:500-525), the one GNN_model.py imports.
 
 Bars (north_star): integer products bit-exact; A*X within 1e-5 relative fp32.  Written as:
   * integer-valued X (X[i,:] = i, the reference's gen_test_tensor idea, GNN_model.py:13-23):
@@ -13,10 +14,16 @@ import numpy as np
 import pytest
 import torch
 
+import frontends
 import hcspmm
 from hcspmm import graphs
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", params=["ctypes", "extension"])
+def fe(request):
+    return frontends.get(request.param)
 
 
 @pytest.fixture(scope="module")
@@ -32,24 +39,28 @@ def _t(a, dev=None):
 
 
 class Graph:
-    def __init__(self, rp, col, dev, rule=0, plan=True, force_type=None):
+    def __init__(self, rp, col, dev, rule=0, plan=True, force_type=None, fe=None):
+        self.fe = fe if fe is not None else frontends.get("ctypes")
         self.rp, self.col = rp, col
         self.N, self.E = len(rp) - 1, len(col)
         self.rp_d, self.col_d = _t(rp, dev), _t(col, dev)
-        outs = hcspmm.preprocess(self.col_d, self.rp_d, self.N, self.E, (self.N + 15) // 16, rule=rule)
+        outs = self.fe.preprocess(self.col_d, self.rp_d, self.N, self.E, (self.N + 15) // 16, rule=rule)
         self.bp, self.e2c, self.e2r, self.ht, self.row_nzr, self.col_nzr = outs
         if force_type is not None:  # force every window onto one sub-path
             self.ht = torch.full_like(self.ht, force_type)
             if plan:  # ... and rebuild the plan for that classification
-                self.row_nzr = hcspmm.build_plan(self.rp_d, self.col_d, self.bp, self.e2c, self.ht)
+                self.row_nzr = self.fe.build_plan(self.rp_d, self.col_d, self.bp, self.e2c, self.ht)
         if not plan:  # the reference's [0] placeholders -> plan-free kernel
             self.row_nzr = torch.zeros(1, dtype=torch.int32, device=dev)
 
     def args(self):
         return (self.rp_d, self.col_d, self.bp, self.e2c, self.e2r, self.ht, self.row_nzr, self.col_nzr)
 
+    def header(self):
+        return self.fe.header(self.row_nzr)
+
     def forward(self, X, fn=None):
-        return (fn or hcspmm.forward)(X, *self.args())[0]
+        return (fn or self.fe.forward)(X, *self.args())[0]
 
 
 def _check(oracle_mod, g, X_np, Z, exact_bits=None):
@@ -62,20 +73,20 @@ def _check(oracle_mod, g, X_np, Z, exact_bits=None):
     ok, ratio = oracle_mod.check_spmm(Z, g.rp, g.col, X_np)
     assert ok, "relative error %.3g x the 1e-5 bar" % ratio
     ref = oracle_mod.spmm_f32(g.rp, g.col, X_np)
-    h = hcspmm.plan_header(g.row_nzr)
+    h = g.header()
     deg = np.diff(g.rp)
     if h is None:  # plan-free kernel: fixed whole-wave threshold; dense windows are MFMA chains
-        seq = deg <= hcspmm.wide_threshold(g.row_nzr, D)
+        seq = deg <= g.fe.wide_threshold(g.row_nzr, D)
         seq |= np.repeat(g.ht.cpu().numpy() != 0, 16)[:g.N]
     else:
-        seq = deg <= min(h.split_threshold, hcspmm.wide_threshold(g.row_nzr, D))
+        seq = deg <= min(h.split_threshold, g.fe.wide_threshold(g.row_nzr, D))
         seq |= np.repeat(g.ht.cpu().numpy() != 0, 16)[:g.N]
     assert np.array_equal(Z[seq], ref[seq]), "sequentially-summed rows differ from the CSR-order fp32 oracle"
     if exact_bits:
         assert seq.all()
 
 
-def test_mfma_operand_layout_single_tile(oracle_mod, dev):
+def test_mfma_operand_layout_single_tile(oracle_mod, dev, fe):
     """Pins the v_mfma_f32_16x16x4_f32 operand/accumulator maps on the box: one dense window with an
     ASYMMETRIC 0/1 tile and X rows holding distinct integers per (row, column)."""
     N = 32
@@ -88,7 +99,7 @@ def test_mfma_operand_layout_single_tile(oracle_mod, dev):
     for D in (16, 64, 20):
         X = (np.arange(N)[:, None] * 100 + np.arange(D)[None, :]).astype(np.float32)
         for plan in (True, False):
-            g = Graph(rp, col, dev, plan=plan, force_type=1)
+            g = Graph(rp, col, dev, plan=plan, force_type=1, fe=fe)
             if plan:
                 assert int(g.ht[0]) == 1  # tiny window -> dense-tile path under the intended rule
             Z = g.forward(_t(X, dev)).cpu().numpy()
@@ -108,9 +119,9 @@ CASES = [
 
 @pytest.mark.parametrize("name,gen,split_free", CASES, ids=[c[0] for c in CASES])
 @pytest.mark.parametrize("D", [32, 128, 256, 16, 22, 7, 96, 1, 300, 1000])
-def test_forward_parity_planned(oracle_mod, dev, name, gen, split_free, D):
+def test_forward_parity_planned(oracle_mod, dev, fe, name, gen, split_free, D):
     rp, col = gen()
-    g = Graph(rp, col, dev)
+    g = Graph(rp, col, dev, fe=fe)
     rng = np.random.default_rng(D)
     X = rng.standard_normal((g.N, D)).astype(np.float32)
     _check(oracle_mod, g, X, g.forward(_t(X, dev)))
@@ -122,12 +133,12 @@ def test_forward_parity_planned(oracle_mod, dev, name, gen, split_free, D):
 @pytest.mark.parametrize("name,gen,split_free", CASES[:4], ids=[c[0] for c in CASES[:4]])
 @pytest.mark.parametrize("D", [32, 128, 22])
 @pytest.mark.parametrize("mode", ["placeholder", "all_sparse", "all_dense"])
-def test_forward_parity_plan_free(oracle_mod, dev, name, gen, split_free, D, mode):
+def test_forward_parity_plan_free(oracle_mod, dev, fe, name, gen, split_free, D, mode):
     """The reference calling convention with row_nzr = col_nzr = [0] (plan-free kernel), with the
     classifier's types and with every window forced onto each sub-path."""
     rp, col = gen()
     force = {"placeholder": None, "all_sparse": 0, "all_dense": 1}[mode]
-    g = Graph(rp, col, dev, plan=False, force_type=force)
+    g = Graph(rp, col, dev, plan=False, force_type=force, fe=fe)
     X = np.random.default_rng(1).standard_normal((g.N, D)).astype(np.float32)
     _check(oracle_mod, g, X, g.forward(_t(X, dev)))  # rows up to 64 entries / dense windows: bit-identical
 
@@ -135,13 +146,13 @@ def test_forward_parity_plan_free(oracle_mod, dev, name, gen, split_free, D, mod
 @pytest.mark.parametrize("name,gen,split_free", CASES[:4], ids=[c[0] for c in CASES[:4]])
 @pytest.mark.parametrize("D", [32, 128, 20])
 @pytest.mark.parametrize("force", [0, 1])
-def test_forward_parity_planned_forced_types(oracle_mod, dev, name, gen, split_free, D, force):
+def test_forward_parity_planned_forced_types(oracle_mod, dev, fe, name, gen, split_free, D, force):
     """Planned kernel with every window forced onto one sub-path.  All-dense exercises dense windows
     far beyond the classifier's reach: hundreds to thousands of condensed columns (the 64-column
     chunk loop of the dense-tile unit) -- still bit-identical to the CSR-order oracle."""
     rp, col = gen()
-    g = Graph(rp, col, dev, force_type=force)
-    h = hcspmm.plan_header(g.row_nzr)
+    g = Graph(rp, col, dev, force_type=force, fe=fe)
+    h = g.header()
     assert (h.n_dense > 0 and h.n_tasks == 0) if force else (h.n_dense == 0)
     if force and name != "planted_dense":
         assert h.max_dense_k > 64
@@ -150,9 +161,9 @@ def test_forward_parity_planned_forced_types(oracle_mod, dev, name, gen, split_f
 
 
 @pytest.mark.parametrize("rule", [0, 1, 2, 3, 4])
-def test_rules_and_aliases(oracle_mod, dev, rule):
+def test_rules_and_aliases(oracle_mod, dev, fe, rule):
     rp, col = graphs.planted_dense_graph(800, seed=9)
-    g = Graph(rp, col, dev, rule=rule)
+    g = Graph(rp, col, dev, rule=rule, fe=fe)
     want = oracle_mod.preprocess(rp, col, rule)
     for w, t in zip(want, (g.bp, g.e2c, g.e2r, g.ht)):
         assert np.array_equal(w, t.cpu().numpy())
@@ -160,17 +171,16 @@ def test_rules_and_aliases(oracle_mod, dev, rule):
     Xd = _t(X, dev)
     Z0 = g.forward(Xd)
     _check(oracle_mod, g, X, Z0)
-    for fn in (hcspmm.forward_more, hcspmm.forward_fixed32, hcspmm.forward_fixed64, hcspmm.backward,
-               hcspmm.backward_fixed32, hcspmm.backward_fixed64):
-        assert torch.equal(g.forward(Xd, fn), Z0)
+    for name in frontends.FORWARD_NAMES:  # every A*X name of the reference's module (hybrid_all.cpp:504-523)
+        assert torch.equal(g.forward(Xd, getattr(fe, name)), Z0), name
 
 
-def test_split_rows_are_deterministic_and_within_tolerance(oracle_mod, dev):
+def test_split_rows_are_deterministic_and_within_tolerance(oracle_mod, dev, fe):
     # star-heavy graph: a few rows with thousands of entries -> segments + fix-up pass
     rp, col = graphs.powerlaw_graph(4000, 120000, seed=5, exponent=1.8, max_degree_frac=0.8)
     assert np.diff(rp).max() > 1024
-    g = Graph(rp, col, dev)
-    h = hcspmm.plan_header(g.row_nzr)
+    g = Graph(rp, col, dev, fe=fe)
+    h = g.header()
     assert h.n_split_rows > 0 and h.n_partials >= 2 * h.n_split_rows
     X = np.random.default_rng(3).standard_normal((g.N, 128)).astype(np.float32)
     Xd = _t(X, dev)
@@ -181,7 +191,7 @@ def test_split_rows_are_deterministic_and_within_tolerance(oracle_mod, dev):
 
 
 @pytest.mark.parametrize("D", [128, 64, 32, 17, 4])
-def test_dense_windows_around_the_compact_record_limit(oracle_mod, dev, D):
+def test_dense_windows_around_the_compact_record_limit(oracle_mod, dev, fe, D):
     """Dense windows with exactly K = 1 ... 40 (compact 64-word records), 41 ... 80 (128-word records) and 81, 96,
     130 (regular packs) unique columns in one graph, last window ragged (N % 16 != 0)."""
     rng = np.random.default_rng(5)
@@ -197,8 +207,8 @@ def test_dense_windows_around_the_compact_record_limit(oracle_mod, dev, D):
         rows.append(16 * w + r)
         cols.append(cset[k])
     rp, col = graphs._to_csr(np.concatenate(rows), np.concatenate(cols), N)
-    g = Graph(rp, col, dev, force_type=1)
-    h = hcspmm.plan_header(g.row_nzr)
+    g = Graph(rp, col, dev, force_type=1, fe=fe)
+    h = g.header()
     uniq = [len(np.unique(col[rp[16 * w]:rp[min(16 * w + 16, N)]])) for w in range(len(Ks))]
     assert h.n_dense == len(Ks) and h.n_dense_compact == sum(8 * ((u + 7) // 8) <= 40 for u in uniq)
     assert h.n_dense_compact2 == sum(40 < 8 * ((u + 7) // 8) <= 80 for u in uniq)
@@ -207,7 +217,7 @@ def test_dense_windows_around_the_compact_record_limit(oracle_mod, dev, D):
 
 
 @pytest.mark.parametrize("D", [128, 32])
-def test_composite_graph_threaded_plan(oracle_mod, dev, D):
+def test_composite_graph_threaded_plan(oracle_mod, dev, fe, D):
     """70 K rows: compact dense windows, tiny / ordinary / wide / split sparse rows in one launch, plan built by
     the multi-threaded host path (>= 4096 windows)."""
     rp, col = graphs.planted_dense_graph_fast(70000, seed=8, dense_fraction=0.4, k_cols=12, fill=0.5, sparse_degree=3)
@@ -217,8 +227,8 @@ def test_composite_graph_threaded_plan(oracle_mod, dev, D):
     extra_r = np.repeat(np.array([17, 30011, 69990]), [700, 1300, 520])
     rp, col = graphs._to_csr(np.concatenate([rows, extra_r]),
                              np.concatenate([col.astype(np.int64), rng.integers(0, N, extra_r.shape[0])]), N)
-    g = Graph(rp, col, dev)
-    h = hcspmm.plan_header(g.row_nzr)
+    g = Graph(rp, col, dev, fe=fe)
+    h = g.header()
     assert h.n_dense_compact > 0 and h.n_tiny > 0 and h.n_split_rows >= 2 and h.n_tasks > h.n_tiny
     X = rng.standard_normal((N, D)).astype(np.float32)
     _check(oracle_mod, g, X, g.forward(_t(X, dev)))
@@ -244,9 +254,9 @@ def _check_h16(oracle_mod, g, X16, Z16):
     D = Xf.shape[1]
     ref32 = oracle_mod.spmm_f32(g.rp, g.col, Xf)
     want = torch.from_numpy(ref32).to(dtype)  # torch rounds to nearest even, like the kernel
-    h = hcspmm.plan_header(g.row_nzr)
+    h = g.header()
     deg = np.diff(g.rp)
-    thr = hcspmm.wide_threshold(g.row_nzr, D, dtype)
+    thr = g.fe.wide_threshold(g.row_nzr, D, dtype)
     seq = deg <= (thr if h is None else min(h.split_threshold, thr))
     seq |= np.repeat(g.ht.cpu().numpy() != 0, 16)[:g.N]
     got = Z16.cpu()
@@ -261,9 +271,9 @@ def _check_h16(oracle_mod, g, X16, Z16):
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
 @pytest.mark.parametrize("D", [256, 128, 64, 40, 32, 20, 7])
 @pytest.mark.parametrize("name,gen", _H16_GRAPHS, ids=[g[0] for g in _H16_GRAPHS])
-def test_half_precision_features_planned(oracle_mod, dev, name, gen, D, dtype):
+def test_half_precision_features_planned(oracle_mod, dev, fe, name, gen, D, dtype):
     rp, col = gen()
-    g = Graph(rp, col, dev)
+    g = Graph(rp, col, dev, fe=fe)
     X16 = torch.from_numpy(np.random.default_rng(D).standard_normal((g.N, D)).astype(np.float32)).to(dtype).to(dev)
     seq = _check_h16(oracle_mod, g, X16, g.forward(X16))
     assert seq.any()
@@ -276,32 +286,32 @@ def test_half_precision_features_planned(oracle_mod, dev, name, gen, D, dtype):
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
 @pytest.mark.parametrize("D", [128, 24, 5])
 @pytest.mark.parametrize("mode", ["plan_free", "all_dense", "all_sparse"])
-def test_half_precision_features_other_paths(oracle_mod, dev, D, dtype, mode):
+def test_half_precision_features_other_paths(oracle_mod, dev, fe, D, dtype, mode):
     rp, col = graphs.powerlaw_graph(1500, 20000, seed=41, max_degree_frac=0.2)
-    g = Graph(rp, col, dev, plan=(mode != "plan_free"), force_type={"all_dense": 1, "all_sparse": 0}.get(mode))
+    g = Graph(rp, col, dev, plan=(mode != "plan_free"), force_type={"all_dense": 1, "all_sparse": 0}.get(mode), fe=fe)
     X16 = torch.from_numpy(np.random.default_rng(7).standard_normal((g.N, D)).astype(np.float32)).to(dtype).to(dev)
     _check_h16(oracle_mod, g, X16, g.forward(X16))
 
 
-def test_half_precision_strided_views_and_errors(oracle_mod, dev):
+def test_half_precision_strided_views_and_errors(oracle_mod, dev, fe):
     rp, col = graphs.powerlaw_graph(900, 12000, seed=43)
-    g = Graph(rp, col, dev)
+    g = Graph(rp, col, dev, fe=fe)
     wide = torch.randn(g.N, 192, device=dev).to(torch.bfloat16)
     out = torch.zeros(g.N, 192, dtype=torch.bfloat16, device=dev)
-    hcspmm.forward_into(wide[:, 64:128], out[:, 128:192], *g.args())
+    fe.forward_into(wide[:, 64:128], out[:, 128:192], *g.args())
     assert torch.equal(out[:, 128:192], g.forward(wide[:, 64:128].contiguous())) and not out[:, :128].any()
     # views whose first element is only 8-byte / 2-byte aligned: the 4- and 1-element-per-lane builds
     for off in (4, 1):
         out.zero_()
-        hcspmm.forward_into(wide[:, off:off + 64], out[:, off:off + 64], *g.args())
+        fe.forward_into(wide[:, off:off + 64], out[:, off:off + 64], *g.args())
         assert torch.equal(out[:, off:off + 64], g.forward(wide[:, off:off + 64].contiguous()))
         assert not out[:, :off].any() and not out[:, off + 64:].any()
     with pytest.raises(RuntimeError, match="float32 / float16 / bfloat16"):
-        hcspmm.forward_into(wide[:, :64], torch.zeros(g.N, 64, device=dev), *g.args())  # mixed dtypes
+        fe.forward_into(wide[:, :64], torch.zeros(g.N, 64, device=dev), *g.args())  # mixed dtypes
     with pytest.raises(RuntimeError, match="float32"):
         g.forward(torch.zeros(g.N, 8, dtype=torch.float64, device=dev))
     with pytest.raises(RuntimeError, match="float32"):  # the fused update stays fp32
-        hcspmm.forward_fixed32_fused(wide[:, :32].contiguous(), *g.args(), torch.zeros(32, 8, device=dev))
+        fe.forward_fixed32_fused(wide[:, :32].contiguous(), *g.args(), torch.zeros(32, 8, device=dev))
 
 
 def _tiny_graph(N=3000, seed=9):
@@ -316,10 +326,10 @@ def _tiny_graph(N=3000, seed=9):
 
 
 @pytest.mark.parametrize("D", [128, 64, 32, 20, 16, 6, 3, 1])
-def test_tiny_tasks_and_tiny_segments(oracle_mod, dev, D):
+def test_tiny_tasks_and_tiny_segments(oracle_mod, dev, fe, D):
     rp, col = _tiny_graph()
-    g = Graph(rp, col, dev, rule=2)  # every window on the sparse-row path
-    h = hcspmm.plan_header(g.row_nzr)
+    g = Graph(rp, col, dev, rule=2, fe=fe)  # every window on the sparse-row path
+    h = g.header()
     deg = np.diff(rp)
     assert h.n_tiny == int((deg <= 2).sum()) + 3 and h.n_split_rows == 3
     X = np.random.default_rng(D).standard_normal((g.N, D)).astype(np.float32)
@@ -330,49 +340,49 @@ def test_tiny_tasks_and_tiny_segments(oracle_mod, dev, D):
 
 
 @pytest.mark.parametrize("D,H", [(32, 32), (64, 64), (96, 22), (32, 7), (16, 40)])
-def test_fused_variants(oracle_mod, dev, D, H):
+def test_fused_variants(oracle_mod, dev, fe, D, H):
     rp, col = graphs.powerlaw_graph(1200, 9000, seed=6)
-    g = Graph(rp, col, dev)
+    g = Graph(rp, col, dev, fe=fe)
     rng = np.random.default_rng(7)
     X = rng.standard_normal((g.N, D)).astype(np.float32)
     W = rng.standard_normal((D, H)).astype(np.float32)
     want_out, want_out2 = oracle_mod.spmm_fused_f32(rp, col, X, W)
     Xd, Wd = _t(X, dev), _t(W, dev)
     scale = oracle_mod.spmm_f64(rp, col, X, absolute=True) @ np.abs(W).astype(np.float64)  # sum|x_j| . |W|
-    for fn in (hcspmm.forward_fixed32_fused, hcspmm.forward_fixed64_fused, hcspmm.forward_GIN_final_fused,
-               hcspmm.backward_fixed32_fused):
-        out, out2 = fn(Xd, *g.args(), Wd)
+    for name in frontends.FUSED_NAMES:
+        out, out2 = getattr(fe, name)(Xd, *g.args(), Wd)
         assert oracle_mod.check_spmm(out2.cpu().numpy(), rp, col, X)[0]
         assert np.all(np.abs(out.cpu().numpy().astype(np.float64) - want_out) <= 1e-5 * scale + 1e-30)
     # transposed (non-contiguous) weights, as the reference's backward passes them (GNN_model.py:98,120)
     Wt_d = _t(np.ascontiguousarray(W.T), dev).transpose(0, 1)
     assert not Wt_d.is_contiguous()
-    out, out2 = hcspmm.forward_fixed32_fused(Xd, *g.args(), Wt_d)
+    out, out2 = fe.forward_fixed32_fused(Xd, *g.args(), Wt_d)
     assert np.all(np.abs(out.cpu().numpy().astype(np.float64) - want_out) <= 1e-5 * scale + 1e-30)
     # final_fused writes the caller's output buffer and returns it
-    buf = torch.zeros(g.N, H, device=dev)
-    out, out2 = hcspmm.forward_final_fused(Xd, *g.args(), Wd, buf)
-    assert out.data_ptr() == buf.data_ptr()
-    assert np.all(np.abs(buf.cpu().numpy().astype(np.float64) - want_out) <= 1e-5 * scale + 1e-30)
+    for name in frontends.FINAL_FUSED_NAMES:
+        buf = torch.zeros(g.N, H, device=dev)
+        out, out2 = getattr(fe, name)(Xd, *g.args(), Wd, buf)
+        assert out.data_ptr() == buf.data_ptr()
+        assert np.all(np.abs(buf.cpu().numpy().astype(np.float64) - want_out) <= 1e-5 * scale + 1e-30)
 
 
 @pytest.mark.parametrize("N,D,H", [(70001, 96, 32), (5000, 32, 32), (9999, 32, 22), (4097, 64, 64), (300, 7, 3),
                                    (66000, 128, 32), (1, 16, 16), (20000, 80, 48)])
-def test_weight_grad_kernel(dev, N, D, H):
+def test_weight_grad_kernel(dev, fe, N, D, H):
     """dW = A^T B (split-K MFMA): against the fp64 product, tolerance 1e-5 * sum_n |a||b| per element (the same kind of
     bar as A*X); deterministic; strided inputs; unsupported shapes decline."""
     rng = np.random.default_rng(N + D)
     A = torch.from_numpy(rng.standard_normal((N, D)).astype(np.float32)).to(dev)
     B = torch.from_numpy(rng.standard_normal((N, H)).astype(np.float32)).to(dev)
-    got = hcspmm.weight_grad(A, B)
+    got = fe.weight_grad(A, B)
     assert got is not None and got.shape == (D, H)
     ref = A.double().t() @ B.double()
     scale = A.double().abs().t() @ B.double().abs()
     assert bool(((got.double() - ref).abs() <= 1e-5 * scale + 1e-30).all())
-    assert torch.equal(got, hcspmm.weight_grad(A, B))
+    assert torch.equal(got, fe.weight_grad(A, B))
     wideA, wideB = torch.zeros(N, D + 5, device=dev), torch.zeros(N, H + 3, device=dev)
     wideA[:, 2:2 + D], wideB[:, 1:1 + H] = A, B
-    assert torch.equal(hcspmm.weight_grad(wideA[:, 2:2 + D], wideB[:, 1:1 + H]), got)
+    assert torch.equal(fe.weight_grad(wideA[:, 2:2 + D], wideB[:, 1:1 + H]), got)
 
 
 def test_weight_grad_declines_unsupported(dev):
@@ -383,20 +393,44 @@ def test_weight_grad_declines_unsupported(dev):
     assert hcspmm.weight_grad(A[:, :16].double(), B.double()) is None
 
 
-def test_error_behaviour(dev):
+def test_error_behaviour(oracle_mod, dev, fe):
     rp, col = graphs.powerlaw_graph(200, 900, seed=1)
-    g = Graph(rp, col, dev)
+    g = Graph(rp, col, dev, fe=fe)
     X = torch.zeros(g.N, 16, device=dev)
     with pytest.raises(RuntimeError, match="input must be contiguous"):
-        hcspmm.forward(X.t().contiguous().t(), *g.args())
+        fe.forward(X.t().contiguous().t(), *g.args())
     with pytest.raises(RuntimeError, match="nodePointer must be a CUDA tensor"):
-        hcspmm.forward(X, g.rp_d.cpu(), *g.args()[1:])
+        fe.forward(X, g.rp_d.cpu(), *g.args()[1:])
     with pytest.raises(RuntimeError, match="rows"):
-        hcspmm.forward(torch.zeros(g.N + 1, 16, device=dev), *g.args())
+        fe.forward(torch.zeros(g.N + 1, 16, device=dev), *g.args())
     # a plan built for another graph is refused (HCSPMM_EPLAN), not silently used
-    other = Graph(*graphs.powerlaw_graph(300, 900, seed=2), dev)
+    other = Graph(*graphs.powerlaw_graph(300, 900, seed=2), dev, fe=fe)
     with pytest.raises(RuntimeError, match="plan"):
-        hcspmm.forward(X, g.rp_d, g.col_d, g.bp, g.e2c, g.e2r, g.ht, other.row_nzr, g.col_nzr)
+        fe.forward(X, g.rp_d, g.col_d, g.bp, g.e2c, g.e2r, g.ht, other.row_nzr, g.col_nzr)
+    # ... also when it has the same N and E (a relabelled graph does): told apart by the graph fingerprint
+    perm = torch.randperm(g.N, generator=torch.Generator().manual_seed(3)).to(torch.int32)
+    rp2, col2 = hcspmm.apply_permutation(torch.from_numpy(rp), torch.from_numpy(col), perm)
+    twin = Graph(rp2.numpy(), col2.numpy(), dev, fe=fe)
+    assert (twin.N, twin.E) == (g.N, g.E)
+    with pytest.raises(RuntimeError, match="plan does not match this graph"):
+        fe.forward(X, g.rp_d, g.col_d, g.bp, g.e2c, g.e2r, g.ht, twin.row_nzr, g.col_nzr)
+    # clones of the SAME graph's tensors (new addresses) pass the fingerprint check -- once, then cached
+    Xr = torch.randn(g.N, 16, device=dev)
+    args = [t.clone() for t in g.args()]
+    for _ in range(2):
+        Z = fe.forward(Xr, *args)[0]
+        assert np.array_equal(Z.cpu().numpy(), oracle_mod.spmm_f32(rp, col, Xr.cpu().numpy()))
+    # a column id beyond X: refused on the host at preprocess, never launched
+    bad = col.copy()
+    bad[len(bad) // 2] = g.N
+    with pytest.raises(RuntimeError, match="invalid argument"):
+        fe.preprocess(_t(bad, dev), g.rp_d, g.N, g.E, (g.N + 15) // 16)
+    # a row block whose columns index a taller X: forward() wants a square product, forward_rect() takes it
+    tall = fe.preprocess(g.col_d, g.rp_d, g.N, g.E, (g.N + 15) // 16, num_columns=2 * g.N)
+    with pytest.raises(RuntimeError, match="rows"):
+        fe.forward(Xr, g.rp_d, g.col_d, *tall)
+    Zt = fe.forward_rect(torch.cat([Xr, Xr]), g.rp_d, g.col_d, *tall)[0]
+    assert torch.equal(Zt, Z)
 
 
 def test_reddit_scale_properties(oracle_mod, dev):
@@ -431,12 +465,12 @@ def test_reddit_scale_properties(oracle_mod, dev):
     assert ok, ratio
 
 
-def test_forward_is_hip_graph_capturable(oracle_mod, dev):
+def test_forward_is_hip_graph_capturable(oracle_mod, dev, fe):
     """hcspmm_forward neither synchronises nor allocates, so a caller may capture it (both launches:
     hybrid kernel + fix-up) into a HIP graph and replay it."""
     rp, col = graphs.powerlaw_graph(3000, 60000, seed=8, max_degree_frac=0.5)
-    g = Graph(rp, col, dev)
-    assert hcspmm.plan_header(g.row_nzr).n_split_rows > 0
+    g = Graph(rp, col, dev, fe=fe)
+    assert g.header().n_split_rows > 0
     X = np.random.default_rng(4).standard_normal((g.N, 64)).astype(np.float32)
     Xd = _t(X, dev)
     g.forward(Xd)  # warm-up outside capture (registers the plan, loads code objects)
@@ -473,7 +507,7 @@ def test_offsets_beyond_2_to_31_elements(dev):
     rp = np.concatenate([[0], np.cumsum(keep.sum(1))]).astype(np.int32)
     col = cols[keep].astype(np.int32)
     g = Graph(rp, col, dev)
-    h = hcspmm.plan_header(g.row_nzr)
+    h = g.header()
     assert h.n_dense >= 99_000 and h.n_tasks > 7_000_000  # planted windows go dense, the rest sparse
     ids = torch.arange(N, device=dev, dtype=torch.float32) % 1021
     X = ids[:, None].expand(N, D).contiguous()
@@ -487,16 +521,16 @@ def test_offsets_beyond_2_to_31_elements(dev):
     torch.cuda.empty_cache()
 
 
-def test_forward_into_strided_views(oracle_mod, dev):
+def test_forward_into_strided_views(oracle_mod, dev, fe):
     """Strided operator: read a column panel of a wider X, write a column panel of a wider Z, in place."""
     rp, col = graphs.planted_dense_graph(1500, seed=4)  # both sub-paths
-    g = Graph(rp, col, dev)
+    g = Graph(rp, col, dev, fe=fe)
     rng = np.random.default_rng(9)
     Xw = rng.standard_normal((g.N, 160)).astype(np.float32)
     Xd = _t(Xw, dev)
     Zd = torch.full((g.N, 200), -7.0, device=dev)
     for (x0, z0, w) in ((32, 64, 64), (0, 0, 32), (96, 136, 20)):
-        hcspmm.forward_into(Xd[:, x0:x0 + w], Zd[:, z0:z0 + w], *g.args())
+        fe.forward_into(Xd[:, x0:x0 + w], Zd[:, z0:z0 + w], *g.args())
         ref = oracle_mod.spmm_f32(rp, col, np.ascontiguousarray(Xw[:, x0:x0 + w]))
         got = Zd.cpu().numpy()
         assert np.array_equal(got[:, z0:z0 + w], ref)
@@ -505,4 +539,74 @@ def test_forward_into_strided_views(oracle_mod, dev):
         Zd[:, z0:z0 + w] = -7.0
         assert np.all(got[:, untouched] == -7.0)
     with pytest.raises(RuntimeError, match="unit inner stride"):
-        hcspmm.forward_into(Xd.t()[:160, :g.N].t()[:, ::2], Zd[:, :80], *g.args())
+        fe.forward_into(Xd.t()[:160, :g.N].t()[:, ::2], Zd[:, :80], *g.args())
+
+
+def _full_size_properties(oracle_mod, dev, rp, col, n_cols, D, fe=None):
+    """Parity at sizes the scalar oracle cannot finish quickly, through size-independent properties (the pattern of
+    test_reddit_scale_properties): exact integer checksums over EVERY row (X = 1 -> degrees; X[i,:] = i mod m with m
+    small enough that every partial sum stays below 2^24, so any summation order is exact), run-to-run determinism,
+    and 2 000 sampled rows against the oracle.  A is n x n_cols (n_cols > n: one GPU's row block of a sharded graph,
+    every X row resident).  Returns the plan header."""
+    fe = fe or frontends.get("ctypes")
+    N, E = len(rp) - 1, len(col)
+    rp_d, col_d = _t(rp, dev), _t(col, dev)
+    outs = fe.preprocess(col_d, rp_d, N, E, (N + 15) // 16, rule=0, num_columns=n_cols)
+    h = fe.header(outs[4])
+    assert h.num_columns == n_cols and h.nnz_sparse + h.nnz_dense == E
+    deg = np.diff(rp)
+    Z = fe.forward_rect(torch.ones(n_cols, D, device=dev), rp_d, col_d, *outs)[0]
+    want = torch.from_numpy(deg.astype(np.float32)).to(dev)
+    assert torch.equal(Z[:, 0], want) and torch.equal(Z[:, D - 1], want) and torch.equal(Z[:, D // 2], want)
+    assert torch.equal(Z, want[:, None].expand(N, D))
+    del Z
+    m = int(min(1021, (2 ** 24) // max(int(deg.max()), 1)))
+    assert m >= 2
+    ids = torch.arange(n_cols, device=dev, dtype=torch.float32) % m
+    X = ids[:, None].expand(n_cols, D).contiguous()
+    Z = fe.forward_rect(X, rp_d, col_d, *outs)[0]
+    cs = np.concatenate([[0.0], np.cumsum((col.astype(np.int64) % m).astype(np.float64))])
+    want = torch.from_numpy((cs[rp[1:]] - cs[rp[:-1]]).astype(np.float32)).to(dev)
+    ht = outs[3]
+    dense_rows = torch.repeat_interleave(ht != 0, 16)[:N]
+    for sel, what in ((dense_rows, "dense-tile rows"), (~dense_rows, "sparse-row rows")):
+        assert torch.equal(Z[sel][:, 0], want[sel]) and torch.equal(Z[sel][:, D - 1], want[sel]), what
+    del X, Z
+    X1 = torch.randn(n_cols, D, device=dev, generator=torch.Generator(device=dev).manual_seed(7))
+    Z1 = fe.forward_rect(X1, rp_d, col_d, *outs)[0]
+    assert torch.equal(Z1, fe.forward_rect(X1, rp_d, col_d, *outs)[0])
+    # sampled rows vs the oracle: a sub-graph of the sampled rows over only the X rows they reference
+    rng = np.random.default_rng(0)
+    rows = np.sort(rng.choice(N, 2000, replace=False))
+    hubs = np.argsort(deg)[-8:]  # plus the heaviest rows (split into segments + fix-up)
+    dense_w = np.nonzero(ht.cpu().numpy())[0][:8]
+    rows = np.unique(np.concatenate([rows, hubs] + [np.arange(16 * w, min(16 * w + 16, N)) for w in dense_w]))
+    sub_col = np.concatenate([col[rp[r]:rp[r + 1]] for r in rows]).astype(np.int64)
+    used, inv = np.unique(sub_col, return_inverse=True)
+    sub_rp = np.concatenate([[0], np.cumsum(deg[rows])]).astype(np.int32)
+    X_sub = X1[torch.from_numpy(used).to(dev)].cpu().numpy()
+    ok, ratio = oracle_mod.check_spmm(Z1[torch.from_numpy(rows).to(dev)].cpu().numpy(), sub_rp, inv.astype(np.int32), X_sub)
+    assert ok, ratio
+    del X1, Z1
+    torch.cuda.empty_cache()
+    return h
+
+
+def test_config4_products_scale_full_size(oracle_mod, dev):
+    """BASELINE config 4 at FULL size on one GPU: 2.45 M nodes / 62 M stored entries, dim 256 (X and Z 2.5 GB each)."""
+    rp, col = graphs.powerlaw_graph(2450000, 62000000, seed=4)
+    assert len(rp) - 1 == 2450000 and abs(len(col) - 62000000) < 62000
+    h = _full_size_properties(oracle_mod, dev, rp, col, 2450000, 256)
+    assert h.n_split_rows > 0 and h.n_tasks > 2000000
+
+
+def test_config5_share_dense_heavy(oracle_mod, dev):
+    """BASELINE config 5 as SURVEY.md 8(d) defines it, one GPU's share: 2 M rows x 16 M columns, 32 M entries, planted
+    16-row groups sharing <= 24 columns -- a majority of windows on the dense-tile path under the reference's
+    classifier (rule 0) -- all 16 M rows of X resident (8.2 GB, N*D = 2.05e9 > 2^31)."""
+    rp, col = graphs.planted_powerlaw_block(2000000, 16000000, 32000000, seed=3)
+    assert len(col) == 32000000 and int(col.max()) > 15_900_000
+    h = _full_size_properties(oracle_mod, dev, rp, col, 16000000, 128)
+    W = 125000
+    assert h.n_dense > 0.6 * W and h.max_dense_k <= 24 and h.n_dense_compact == h.n_dense
+    assert h.nnz_dense > 0.4 * len(col) and h.nnz_sparse > 0.4 * len(col)  # both sub-paths carry real work

@@ -149,11 +149,20 @@ extern "C" int hcspmm_graph_fingerprint_device(const int32_t* rowptr, const int3
 }
 extern "C" int hcspmm_last_hip_error(void) { return g_last_hip_error; }
 
-extern "C" int hcspmm_forward_typed(const void* X, int64_t x_rows, int64_t ldx, void* Z, int64_t ldz, int dtype, const int32_t* rowptr,
-                                    const int32_t* col, const int32_t* blockPartition, const int32_t* edgeToColumn,
-                                    const int32_t* edgeToRow, const int32_t* hybrid_type, const int32_t* plan_d,
-                                    const hcspmm_plan_header* ph, int64_t N, int64_t E, int D, void* workspace,
-                                    size_t workspace_bytes, void* stream_v) {
+namespace {
+// weights / output of a fused launch (dense-tile windows multiply their tile by W inside the hybrid kernel)
+struct FusedOperands {
+  const float* W;
+  long long ldr, ldc;
+  float* out;
+  int H;
+};
+
+int forward_impl(const void* X, int64_t x_rows, int64_t ldx, void* Z, int64_t ldz, int dtype, const int32_t* rowptr,
+                 const int32_t* col, const int32_t* blockPartition, const int32_t* edgeToColumn,
+                 const int32_t* edgeToRow, const int32_t* hybrid_type, const int32_t* plan_d,
+                 const hcspmm_plan_header* ph, int64_t N, int64_t E, int D, void* workspace,
+                 size_t workspace_bytes, void* stream_v, const FusedOperands* fused) {
   if (dtype < HCSPMM_DTYPE_F32 || dtype > HCSPMM_DTYPE_BF16) return HCSPMM_EINVAL;
   if (N < 0 || E < 0 || D <= 0 || ldx < D || ldz < D) return HCSPMM_EINVAL;
   if (N == 0) return HCSPMM_OK;
@@ -196,11 +205,20 @@ extern "C" int hcspmm_forward_typed(const void* X, int64_t x_rows, int64_t ldx, 
     a.D = D;
     a.sparse_wgs = 0;
     a.n_panels = 0;
+    a.fused = fused ? 1 : 0;
+    a.fused_dense_wgs = 0;
+    a.H = fused ? fused->H : 0;
+    a.W = fused ? fused->W : nullptr;
+    a.w_ldr = fused ? fused->ldr : 0;
+    a.w_ldc = fused ? fused->ldc : 0;
+    a.out = fused ? fused->out : nullptr;
     const int vec = pick_vec(dtype, D, ldx, ldz, X, Z, need ? workspace : nullptr);
+    if (fused && (vec != 4 || dtype != HCSPMM_DTYPE_F32)) return HCSPMM_EINVAL;  // (fused_single_launch_ok said otherwise)
     e = dtype == HCSPMM_DTYPE_F32 ? hcspmm::launch_plan_f32(a, vec, stream)
         : dtype == HCSPMM_DTYPE_F16 ? hcspmm::launch_plan_f16(a, vec, stream)
                                     : hcspmm::launch_plan_bf16(a, vec, stream);
   } else {
+    if (fused) return HCSPMM_EINVAL;
     if (plan_d || ph) return HCSPMM_EINVAL;  // both or neither
     if (!blockPartition || !hybrid_type || (E > 0 && (!edgeToColumn || !edgeToRow))) return HCSPMM_EINVAL;
     hcspmm::WindowArgs a;
@@ -223,6 +241,16 @@ extern "C" int hcspmm_forward_typed(const void* X, int64_t x_rows, int64_t ldx, 
   }
   return e == hipSuccess ? HCSPMM_OK : fail_hip(e);
 }
+}  // namespace
+
+extern "C" int hcspmm_forward_typed(const void* X, int64_t x_rows, int64_t ldx, void* Z, int64_t ldz, int dtype, const int32_t* rowptr,
+                                    const int32_t* col, const int32_t* blockPartition, const int32_t* edgeToColumn,
+                                    const int32_t* edgeToRow, const int32_t* hybrid_type, const int32_t* plan_d,
+                                    const hcspmm_plan_header* ph, int64_t N, int64_t E, int D, void* workspace,
+                                    size_t workspace_bytes, void* stream_v) {
+  return forward_impl(X, x_rows, ldx, Z, ldz, dtype, rowptr, col, blockPartition, edgeToColumn, edgeToRow, hybrid_type,
+                      plan_d, ph, N, E, D, workspace, workspace_bytes, stream_v, nullptr);
+}
 
 extern "C" int hcspmm_forward_strided(const float* X, int64_t x_rows, int64_t ldx, float* Z, int64_t ldz, const int32_t* rowptr,
                                       const int32_t* col, const int32_t* blockPartition, const int32_t* edgeToColumn,
@@ -241,6 +269,28 @@ extern "C" int hcspmm_forward(const float* X, float* Z, const int32_t* rowptr, c
                                 N, E, D, workspace, workspace_bytes, stream_v);
 }
 
+// Single-launch form of the fused operators: the dense-tile windows of a planned launch multiply their tile by the
+// weights while it is in the MFMA accumulators (spmm_impl.h fused_dense_region); only the windows on the sparse-row
+// path -- listed in the plan (off_sparse_windows) -- go through the update kernel afterwards.  Taken when the plan
+// has dense windows and the shape is in range: fp32, D and H multiples of 16, H <= 64, W fits the LDS staging
+// area, 16-byte aligned rows.  HCSPMM_FUSED_SINGLE_LAUNCH=0 restores the two-launch form (A/B: profiles/r02/ab_fused.log).
+static bool fused_single_launch_ok(const hcspmm_plan_header* ph, const void* X, const void* out2, int D, int H) {
+  static const bool enabled = [] {
+    const char* e = getenv("HCSPMM_FUSED_SINGLE_LAUNCH");
+    return !(e && e[0] == '0');
+  }();
+  if (!enabled || !ph || ph->n_dense <= 0) return false;
+  if (D % 16 != 0 || D < 32 || H % 16 != 0 || H > 32 || H <= 0) return false;
+  if (!aligned(X, 16) || !aligned(out2, 16)) return false;
+  const int dv = D >= 64 ? 4 : 2;
+  const int rows = (D + 16 * dv - 1) / (16 * dv) * 16 * dv;
+  return (size_t)rows * (size_t)(H + 4) * sizeof(float) <= 64 * 1024;
+}
+
+extern "C" int hcspmm_fused_in_launch(const hcspmm_plan_header* ph, int D, int H) {
+  return fused_single_launch_ok(ph, nullptr, nullptr, D, H) ? 1 : 0;  // (null pointers count as aligned)
+}
+
 extern "C" int hcspmm_forward_fused(const float* X, float* out, float* out2, const float* weights, int64_t ldr,
                                     int64_t ldc, int H, const int32_t* rowptr, const int32_t* col,
                                     const int32_t* blockPartition, const int32_t* edgeToColumn,
@@ -248,11 +298,22 @@ extern "C" int hcspmm_forward_fused(const float* X, float* out, float* out2, con
                                     const hcspmm_plan_header* ph, int64_t N, int64_t E, int D, void* workspace,
                                     size_t workspace_bytes, void* stream_v) {
   if (!out || !out2 || !weights || H <= 0) return HCSPMM_EINVAL;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+  if (plan_d && ph && fused_single_launch_ok(ph, X, out2, D, H)) {
+    const FusedOperands f{weights, (long long)ldr, (long long)ldc, out, H};
+    const int rc = forward_impl(X, N, D, out2, D, HCSPMM_DTYPE_F32, rowptr, col, blockPartition, edgeToColumn, edgeToRow,
+                                hybrid_type, plan_d, ph, N, E, D, workspace, workspace_bytes, stream_v, &f);
+    if (rc != HCSPMM_OK) return rc;
+    if (ph->n_sparse_windows == 0) return HCSPMM_OK;
+    const hipError_t e = hcspmm::launch_dense_update(out2, weights, (long long)ldr, (long long)ldc, out, (int)N, D, H,
+                                                     plan_d + ph->off_sparse_windows, ph->n_sparse_windows, stream);
+    return e == hipSuccess ? HCSPMM_OK : fail_hip(e);
+  }
   const int rc = hcspmm_forward(X, out2, rowptr, col, blockPartition, edgeToColumn, edgeToRow, hybrid_type, plan_d, ph,
                                 N, E, D, workspace, workspace_bytes, stream_v);
   if (rc != HCSPMM_OK) return rc;
-  const hipError_t e = hcspmm::launch_dense_update(out2, weights, (long long)ldr, (long long)ldc, out, (int)N, D, H,
-                                                   reinterpret_cast<hipStream_t>(stream_v));
+  const hipError_t e = hcspmm::launch_dense_update(out2, weights, (long long)ldr, (long long)ldc, out, (int)N, D, H, nullptr, 0,
+                                                   stream);
   return e == hipSuccess ? HCSPMM_OK : fail_hip(e);
 }
 

@@ -33,6 +33,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "hcspmm.h"
 #include "spmm_kernels.h"
@@ -162,6 +163,9 @@ template <int L> struct TinyT {
   static constexpr int per_group = HCSPMM_TINY_PER_WAVE / (64 / L);
   static constexpr int value = per_group < 2 ? 2 : (per_group > 4 ? 4 : per_group);
 };
+#ifndef HCSPMM_FUSED_MIN_WAVES
+#define HCSPMM_FUSED_MIN_WAVES 4
+#endif
 #ifndef HCSPMM_MIN_WAVES_PER_SIMD
 #define HCSPMM_MIN_WAVES_PER_SIMD 4  // <= 128 registers per lane (measured best with U = B = 8: profiles/r01/ab_u_b_mw_v2.log)
 #endif
@@ -346,19 +350,23 @@ __device__ __forceinline__ void dense_store(typename E::T* __restrict__ Z, const
   }
 }
 
-template <typename E, int VEC>
-__device__ __forceinline__ void dense_unit(const typename E::T* __restrict__ X, typename E::T* __restrict__ Z,
-                                           const int* __restrict__ U, cu64_p masks, int K4, int window, int panel,
-                                           int N, int D, size_t ldx, size_t ldz, int lane) {
-  typedef Lane<E, VEC> Ln;
-  const int kq = lane >> 4, j = lane & 15;
-  const int c = panel * 16 * VEC + j * VEC;
-  const bool cok = c < D;
-  const int csafe = cok ? c : 0;
-  f32x4 acc[VEC];
-#pragma unroll
-  for (int q = 0; q < VEC; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+// TR = false: acc holds the 16 x (16*VEC) tile in the MFMA C layout described above (dense_store writes it).
+// TR = true (fused aggregate+update): the operands are exchanged -- A operand = the gathered X values, B operand =
+// the 0/1 tile -- so the matrix core produces the TRANSPOSED tile: lane l, register r of acc[q] holds
+// Z[row l & 15][panel + (4*(l >> 4) + r)*VEC + q].  Same products, same k order => the same bits; the point is that
+// a lane now holds ONE row's values, indexed by l >> 4, which is exactly the A-operand shape of the following
+// (tile x weights) MFMAs -- the tile never leaves the registers (fused_epilogue).
+template <bool TR>
+__device__ __forceinline__ f32x4 tile_mfma(float a01, float x, f32x4 acc) {
+  if constexpr (TR) return __builtin_amdgcn_mfma_f32_16x16x4f32(x, a01, acc, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x4f32(a01, x, acc, 0, 0, 0);
+}
 
+template <typename E, int VEC, bool TR>
+__device__ __forceinline__ void dense_chain(const typename E::T* __restrict__ X, const int* __restrict__ U, cu64_p masks,
+                                            int K4, int csafe, bool cok, size_t ldx, int lane, f32x4 (&acc)[VEC]) {
+  typedef Lane<E, VEC> Ln;
+  const int kq = lane >> 4;
   for (int kb = 0; kb < K4; kb += 16) {
     const int myU = (kb * 4 + lane < K4 * 4) ? U[kb * 4 + lane] : -1;
     const int steps = min(16, K4 - kb);
@@ -385,12 +393,25 @@ __device__ __forceinline__ void dense_unit(const typename E::T* __restrict__ X, 
         if (!(cok && idx[u] >= 0)) x[u] = Ln::zero();
         if (t0 + u < steps) {  // wave-uniform: no MFMA issue slots for the padding of a short batch
 #pragma unroll
-          for (int q = 0; q < VEC; ++q)
-            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], Ln::elem(x[u], q), acc[q], 0, 0, 0);
+          for (int q = 0; q < VEC; ++q) acc[q] = tile_mfma<TR>(a[u], Ln::elem(x[u], q), acc[q]);
         }
       }
     }
   }
+}
+
+template <typename E, int VEC>
+__device__ __forceinline__ void dense_unit(const typename E::T* __restrict__ X, typename E::T* __restrict__ Z,
+                                           const int* __restrict__ U, cu64_p masks, int K4, int window, int panel,
+                                           int N, int D, size_t ldx, size_t ldz, int lane) {
+  const int kq = lane >> 4, j = lane & 15;
+  const int c = panel * 16 * VEC + j * VEC;
+  const bool cok = c < D;
+  const int csafe = cok ? c : 0;
+  f32x4 acc[VEC];
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  dense_chain<E, VEC, false>(X, U, masks, K4, csafe, cok, ldx, lane, acc);
   if (cok) dense_store<E, VEC>(Z, acc, window, kq, c, N, ldz);
 }
 
@@ -416,7 +437,7 @@ template <int C> struct Rec {
   }
 };
 
-template <typename E, int VEC, int C, int KMAX, int STEPS, int T0>
+template <typename E, int VEC, int C, int KMAX, int STEPS, int T0, bool TR = false>
 struct CompactSteps {
   template <int U> static __device__ __forceinline__ void meta(const Rec<C>& rec, int K4, int kq, int lane, int* idx, float* a) {
     if constexpr (U < STEPS) {
@@ -444,11 +465,33 @@ struct CompactSteps {
       if (!(cok && idx[u] >= 0)) x[u] = Ln::zero();
       if (T0 + u < K4) {  // wave-uniform
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], Ln::elem(x[u], q), acc[q], 0, 0, 0);
+        for (int q = 0; q < VEC; ++q) acc[q] = tile_mfma<TR>(a[u], Ln::elem(x[u], q), acc[q]);
       }
     }
   }
 };
+
+// the MFMA chain of a compact record (K4 k-steps), any operand order
+template <typename E, int VEC, int C, bool TR>
+__device__ __forceinline__ void compact_chain(const typename E::T* __restrict__ X, const Rec<C>& rec, int K4, int csafe,
+                                              bool cok, size_t ldx, int lane, f32x4 (&acc)[VEC]) {
+  constexpr int KMAX = C == 1 ? HCSPMM_COMPACT_K : HCSPMM_COMPACT2_K;
+  if constexpr (C == 1) {  // K4 <= 10
+    if (K4 <= 2) CompactSteps<E, VEC, C, KMAX, 2, 0, TR>::run(X, rec, K4, csafe, cok, ldx, lane, acc);
+    else if (K4 <= 4) CompactSteps<E, VEC, C, KMAX, 4, 0, TR>::run(X, rec, K4, csafe, cok, ldx, lane, acc);
+    else {
+      CompactSteps<E, VEC, C, KMAX, 8, 0, TR>::run(X, rec, K4, csafe, cok, ldx, lane, acc);
+      if (K4 > 8) CompactSteps<E, VEC, C, KMAX, 2, 8, TR>::run(X, rec, K4, csafe, cok, ldx, lane, acc);  // K = 40
+    }
+  } else {  // 12 <= K4 <= 20
+    CompactSteps<E, VEC, C, KMAX, 8, 0, TR>::run(X, rec, K4, csafe, cok, ldx, lane, acc);
+    if (K4 <= 12) CompactSteps<E, VEC, C, KMAX, 4, 8, TR>::run(X, rec, K4, csafe, cok, ldx, lane, acc);
+    else {
+      CompactSteps<E, VEC, C, KMAX, 8, 8, TR>::run(X, rec, K4, csafe, cok, ldx, lane, acc);
+      if (K4 > 16) CompactSteps<E, VEC, C, KMAX, 4, 16, TR>::run(X, rec, K4, csafe, cok, ldx, lane, acc);
+    }
+  }
+}
 
 template <typename E, int VEC, int C>
 __device__ __forceinline__ void dense_compact_unit(const typename E::T* __restrict__ X, typename E::T* __restrict__ Z,
@@ -468,22 +511,143 @@ __device__ __forceinline__ void dense_compact_unit(const typename E::T* __restri
   f32x4 acc[VEC];
 #pragma unroll
   for (int q = 0; q < VEC; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if constexpr (C == 1) {  // K4 <= 10
-    if (K4 <= 2) CompactSteps<E, VEC, C, KMAX, 2, 0>::run(X, rec, K4, csafe, cok, ldx, lane, acc);
-    else if (K4 <= 4) CompactSteps<E, VEC, C, KMAX, 4, 0>::run(X, rec, K4, csafe, cok, ldx, lane, acc);
-    else {
-      CompactSteps<E, VEC, C, KMAX, 8, 0>::run(X, rec, K4, csafe, cok, ldx, lane, acc);
-      if (K4 > 8) CompactSteps<E, VEC, C, KMAX, 2, 8>::run(X, rec, K4, csafe, cok, ldx, lane, acc);  // K = 40
-    }
-  } else {  // 12 <= K4 <= 20
-    CompactSteps<E, VEC, C, KMAX, 8, 0>::run(X, rec, K4, csafe, cok, ldx, lane, acc);
-    if (K4 <= 12) CompactSteps<E, VEC, C, KMAX, 4, 8>::run(X, rec, K4, csafe, cok, ldx, lane, acc);
-    else {
-      CompactSteps<E, VEC, C, KMAX, 8, 8>::run(X, rec, K4, csafe, cok, ldx, lane, acc);
-      if (K4 > 16) CompactSteps<E, VEC, C, KMAX, 4, 16>::run(X, rec, K4, csafe, cok, ldx, lane, acc);
+  compact_chain<E, VEC, C, false>(X, rec, K4, csafe, cok, ldx, lane, acc);
+  if (cok) dense_store<E, VEC>(Z, acc, window, kq, c, N, ldz);
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused aggregate + update for dense-tile windows (hcspmm_forward_fused; replaces the second stage of the
+// reference's fused kernels, hybrid_all_kernel.cu:1807-1837 and its siblings, which keep the aggregated tile in
+// shared memory as WMMA A-operand blocks).  Here the tile never leaves the registers: the aggregation runs with
+// exchanged MFMA operands (TR = true above), so lane l, register r of acc[q] holds tile[row l & 15][feature
+// f(l >> 4, r, q)], f = panel + (4*(l >> 4) + r)*DV + q -- one row per lane, the feature indexed by l >> 4: the
+// A-operand shape.  The update is then 4*DV MFMA steps per 16-column output tile, step (r, q) contracting over
+// the four features f(0..3, r, q) with B operand W[f(l >> 4, r, q)][16*t + (l & 15)] read from LDS (W is staged
+// once per workgroup, zero-padded to whole panels; the row stride HS makes the four l >> 4 groups hit disjoint
+// banks).  One wave owns a WINDOW (all its column panels in turn, out accumulated across them); out2 = A*X is
+// written from the transposed layout (each lane stores 4*DV consecutive floats of its row).  The contraction
+// order over the D features is a fixed permutation => deterministic; out2 has the unfused kernel's bits.
+// ------------------------------------------------------------------------------------------
+
+__host__ __device__ inline int fused_row_stride(int H, int dv) { return H + (dv >= 4 ? 1 : (dv == 2 ? 2 : 4)); }
+
+template <int DV, int HT>  // H == 16*HT exactly: no guards, so the whole update of a panel is one basic block
+__device__ __forceinline__ void fused_epilogue(const f32x4 (&acc)[DV], const float* __restrict__ s_w, int HS, int panel,
+                                               int lane, f32x4 (&oacc)[HT]) {
+  const int kq = lane >> 4, n = lane & 15;
+  const float* wbase = s_w + (panel * 16 * DV + 4 * kq * DV) * HS + n;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float w[DV][HT];  // the LDS reads of a step group are issued together, ahead of its MFMAs
+#pragma unroll
+    for (int q = 0; q < DV; ++q)
+#pragma unroll
+      for (int t = 0; t < HT; ++t) w[q][t] = wbase[(r * DV + q) * HS + 16 * t];
+#pragma unroll
+    for (int q = 0; q < DV; ++q)
+#pragma unroll
+      for (int t = 0; t < HT; ++t) oacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[q][r], w[q][t], oacc[t], 0, 0, 0);
+  }
+}
+
+template <int DV>
+__device__ __forceinline__ void store_tile_transposed(float* __restrict__ Z, const f32x4 (&acc)[DV], int window, int panel,
+                                                      int N, int D, size_t ldz, int lane) {
+  typedef Lane<F32, DV> Ln;
+  const int kq = lane >> 4, row = window * 16 + (lane & 15);
+  if (row >= N) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int c = panel * 16 * DV + (4 * kq + r) * DV;
+    if (c < D) {
+      typename Ln::acc_t o;
+#pragma unroll
+      for (int q = 0; q < DV; ++q) aset(o, q, acc[q][r]);
+      // a lane's four stores together cover 16*DV consecutive bytes, but one store instruction writes 16-byte
+      // pieces 64*DV bytes apart: plain (cached) stores, so that the L2 assembles whole lines before they leave
+      *reinterpret_cast<typename Ln::acc_t*>(Z + (size_t)row * ldz + c) = o;
     }
   }
-  if (cok) dense_store<E, VEC>(Z, acc, window, kq, c, N, ldz);
+}
+
+template <int DV, int HT>  // HT = H / 16 output tiles, held in registers
+__device__ __forceinline__ void fused_dense_window(const PlanArgs& a, int unit, const float* __restrict__ s_w, int HS,
+                                                   int lane) {
+  const float* X = reinterpret_cast<const float*>(a.X);
+  float* Z = reinterpret_cast<float*>(a.Z);
+  const int kq = lane >> 4, j = lane & 15;
+  const int n_reg = a.n_dense - a.n_dense_compact - a.n_dense_compact2;
+  f32x4 oacc[HT];
+#pragma unroll
+  for (int t = 0; t < HT; ++t) oacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int window;
+  // one panel: aggregate (transposed tile in acc), write out2, chain the update MFMAs
+#define HCSPMM_FUSED_PANELS(CHAIN)                                                        \
+  for (int panel = 0; panel < a.n_panels; ++panel) {                                      \
+    const int c = panel * 16 * DV + j * DV;                                               \
+    const bool cok = c < a.D;                                                             \
+    const int csafe = cok ? c : 0;                                                        \
+    f32x4 acc[DV];                                                                        \
+    _Pragma("unroll") for (int q = 0; q < DV; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};    \
+    CHAIN;                                                                                \
+    store_tile_transposed<DV>(Z, acc, window, panel, a.N, a.D, a.ldz, lane);              \
+    fused_epilogue<DV, HT>(acc, s_w, HS, panel, lane, oacc);                              \
+  }
+  if (unit < n_reg) {
+    cint_p dix = (cint_p)(a.plan + a.off_dense_index) + 4 * unit;  // wave-uniform: scalar loads
+    window = dix[0];
+    const int K4 = dix[2];
+    const int* U = a.plan + a.off_dense_pack + dix[1];
+    cu64_p masks = (cu64_p)(U + 4 * K4);
+    HCSPMM_FUSED_PANELS((dense_chain<F32, DV, true>(X, U, masks, K4, csafe, cok, a.ldx, lane, acc)))
+  } else if (unit < n_reg + a.n_dense_compact2) {
+    Rec<2> rec;
+    const int* recp = a.plan + a.off_dense_compact2 + (unit - n_reg) * HCSPMM_COMPACT2_WORDS;
+    rec.w[0] = recp[lane];
+    rec.w[1] = recp[64 + lane];
+    window = rec.template scalar<0>();
+    const int K4 = rec.template scalar<1>();
+    HCSPMM_FUSED_PANELS((compact_chain<F32, DV, 2, true>(X, rec, K4, csafe, cok, a.ldx, lane, acc)))
+  } else {
+    Rec<1> rec;
+    rec.w[0] = (a.plan + a.off_dense_compact + (unit - n_reg - a.n_dense_compact2) * HCSPMM_COMPACT_WORDS)[lane];
+    window = rec.template scalar<0>();
+    const int K4 = rec.template scalar<1>();
+    HCSPMM_FUSED_PANELS((compact_chain<F32, DV, 1, true>(X, rec, K4, csafe, cok, a.ldx, lane, acc)))
+  }
+#undef HCSPMM_FUSED_PANELS
+  // out: accumulator register r of lane (kq, j) is out[row 4*kq + r][16*t + j]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = window * 16 + 4 * kq + r;
+    if (row < a.N) {
+#pragma unroll
+      for (int t = 0; t < HT; ++t) a.out[(size_t)row * (size_t)(16 * HT) + 16 * t + j] = oacc[t][r];
+    }
+  }
+}
+
+// the dense region of a fused launch: stage W in LDS (every wave of the workgroup takes part), then the workgroup's
+// waves stride over the dense windows, one window per wave at a time
+template <int DV, int HT>
+__device__ __forceinline__ void fused_dense_loop(const PlanArgs& a, const float* __restrict__ s_w, int HS, int lane, int wave) {
+  for (int unit = ((int)blockIdx.x - a.sparse_wgs) * kWaves + wave; unit < a.n_dense; unit += a.fused_dense_wgs * kWaves)
+    fused_dense_window<DV, HT>(a, unit, s_w, HS, lane);
+}
+
+__device__ __forceinline__ void fused_dense_region(const PlanArgs& a, int lane, int wave) {
+  extern __shared__ __attribute__((aligned(16))) float s_fused_w[];
+  const int dv = a.dense_vec;
+  const int HS = fused_row_stride(a.H, dv);
+  const int rows = a.n_panels * 16 * dv;  // D rounded up to whole panels; the padding rows are zero
+  for (int i = threadIdx.x; i < rows * a.H; i += kThreads) {
+    const int k = i / a.H, h = i - k * a.H;
+    s_fused_w[k * HS + h] = k < a.D ? a.W[(long long)k * a.w_ldr + (long long)h * a.w_ldc] : 0.0f;
+  }
+  __syncthreads();
+  // W is staged once per workgroup, so the region is a bounded number of workgroups that stride over the windows
+  if (dv == 4) a.H == 32 ? fused_dense_loop<4, 2>(a, s_fused_w, HS, lane, wave) : fused_dense_loop<4, 1>(a, s_fused_w, HS, lane, wave);
+  else a.H == 32 ? fused_dense_loop<2, 2>(a, s_fused_w, HS, lane, wave) : fused_dense_loop<2, 1>(a, s_fused_w, HS, lane, wave);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -501,7 +665,7 @@ template <int VEC> struct DenseV {
   static constexpr int mid = VEC >= 8 ? 4 : (VEC >= 4 ? 2 : 1);  // fp32: 4 -> 2; 16-bit: 8 -> 4
 };
 
-template <typename E, int L, int VEC, int UNROLL, int MINW>
+template <typename E, int L, int VEC, int UNROLL, int MINW, bool FUSED = false>
 __global__ __launch_bounds__(kThreads, MINW) void hybrid_plan_kernel(PlanArgs a) {
   typedef typename E::T elem_t;
   const elem_t* X = reinterpret_cast<const elem_t*>(a.X);
@@ -547,6 +711,10 @@ __global__ __launch_bounds__(kThreads, MINW) void hybrid_plan_kernel(PlanArgs a)
       sparse_task<E, L, VEC, false, UNROLL>(X, dz, dp, a.col, e0, n, a.ldx, c0, cend, lane);
     }
   } else {
+    if constexpr (FUSED) {  // fp32 only: dense windows aggregate AND multiply by the weights (one window per wave)
+      fused_dense_region(a, lane, wave);
+      return;
+    }
     constexpr int VM = DenseV<VEC>::mid;
     int unit = ((int)blockIdx.x - a.sparse_wgs) * kWaves + wave;
     if (unit >= a.n_dense * a.n_panels) return;
@@ -756,13 +924,36 @@ static hipError_t launch_plan_LV(const PlanArgs& a, hipStream_t stream) {
   constexpr int kMidCols = (sizeof(typename E::T) == 2 && VM > 1) ? 8 * VM : 16 * VM;
   b.dense_vec = (a.D >= 16 * VEC) ? VEC : (a.D >= kMidCols ? VM : 1);
   b.n_panels = (a.D + 16 * b.dense_vec - 1) / (16 * b.dense_vec);
-  const long long dense_units = (long long)a.n_dense * b.n_panels;
-  const long long dense_wgs = (dense_units + kWaves - 1) / kWaves;
+  constexpr bool kCanFuse = sizeof(typename E::T) == 4 && VEC == 4;
+  if (a.fused && !kCanFuse) return hipErrorInvalidValue;  // the caller checked (capi.hip fused_single_launch_ok)
+  const long long dense_units = (long long)a.n_dense * (a.fused ? 1 : b.n_panels);  // fused: a wave owns a window
+  long long dense_wgs = (dense_units + kWaves - 1) / kWaves;
+  if (a.fused) {
+    static const long long cap = [] {
+      const char* e = getenv("HCSPMM_FUSED_DENSE_WGS");
+      const long long v = e ? atoll(e) : 0;
+      return v > 0 ? v : 2048LL;
+    }();
+    if (dense_wgs > cap) dense_wgs = cap;
+  }
+  b.fused_dense_wgs = (int)dense_wgs;
   const long long grid = (long long)b.sparse_wgs + dense_wgs;
   if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
   if (grid > 0) {
-    hipLaunchKernelGGL((hybrid_plan_kernel<E, L, VEC, HCSPMM_SPARSE_U, HCSPMM_MIN_WAVES_PER_SIMD>), dim3((unsigned)grid),
-                       dim3(kThreads), 0, stream, b);
+    if constexpr (kCanFuse) {
+      if (a.fused) {
+        const size_t lds = (size_t)b.n_panels * 16 * b.dense_vec * fused_row_stride(a.H, b.dense_vec) * sizeof(float);
+        // (four waves per SIMD, like the plain kernel: at three -- 137 registers, nothing spilled -- the in-launch form LOSES 2-10 %: profiles/r02/ab_fused.log)
+        hipLaunchKernelGGL((hybrid_plan_kernel<E, L, VEC, HCSPMM_SPARSE_U, HCSPMM_FUSED_MIN_WAVES, true>),
+                           dim3((unsigned)grid), dim3(kThreads), lds, stream, b);
+      } else {
+        hipLaunchKernelGGL((hybrid_plan_kernel<E, L, VEC, HCSPMM_SPARSE_U, HCSPMM_MIN_WAVES_PER_SIMD>), dim3((unsigned)grid),
+                           dim3(kThreads), 0, stream, b);
+      }
+    } else {
+      hipLaunchKernelGGL((hybrid_plan_kernel<E, L, VEC, HCSPMM_SPARSE_U, HCSPMM_MIN_WAVES_PER_SIMD>), dim3((unsigned)grid),
+                         dim3(kThreads), 0, stream, b);
+    }
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;

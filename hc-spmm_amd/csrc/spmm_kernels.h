@@ -27,6 +27,14 @@ struct PlanArgs {
   int sparse_wgs_pp, dense_vec;        // filled by the launcher
   int wide_wgs, sparse_wgs, n_panels;  // filled by the launcher
   int tiny_wgs;                        // filled by the launcher: workgroups of the tiny-task region (per panel)
+  // fused aggregate+update (hcspmm_forward_fused, fp32 only): when fused != 0 every dense-tile window also
+  // multiplies its 16 x D tile by the weights while it is still in the MFMA accumulators and writes 16 rows of
+  // out (N x H, row-major); Z is then the operator's out2.  W: D x H with element strides (w_ldr, w_ldc).
+  int fused, H;
+  int fused_dense_wgs;  // filled by the launcher: workgroups of the fused dense region (each strides over windows)
+  const float* W;
+  long long w_ldr, w_ldc;
+  float* out;
 };
 
 // Arguments of the plan-free launch: the reference's seven graph tensors as they are.
@@ -59,8 +67,14 @@ int weight_grad_groups(long long N);
 hipError_t launch_weight_grad(const float* A, long long lda, const float* B, long long ldb, float* out, float* partial,
                               long long N, int D, int H, hipStream_t stream);
 
-// out[N x H] = in[N x D] * W (D x H, element strides ldr / ldc), fp32 MFMA.
+// out[N x H] = in[N x D] * W (D x H, element strides ldr / ldc), fp32 MFMA.  tile_list (device, n_tiles ids of
+// 16-row tiles) restricts the product to those tiles (the windows a fused launch has not already multiplied);
+// nullptr = every tile.
 hipError_t launch_dense_update(const float* in, const float* W, long long ldr, long long ldc, float* out, int N,
-                               int D, int H, hipStream_t stream);
+                               int D, int H, const int* tile_list, int n_tiles, hipStream_t stream);
+// true when launch_dense_update takes the LDS-staged streaming kernel for this shape (the shapes the single-launch
+// fused dense-tile epilogue is built for as well)
+bool dense_update_streams(const float* in, const float* out, int D, int H);
+
 
 }  // namespace hcspmm

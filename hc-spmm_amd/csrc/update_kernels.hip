@@ -21,10 +21,13 @@ constexpr int kMaxTiles = 8;  // 16-column output tiles kept in registers per pa
 __global__ __launch_bounds__(kUpdWaves * 64) void dense_update_kernel(const float* __restrict__ in,
                                                                       const float* __restrict__ W, long long ldr,
                                                                       long long ldc, float* __restrict__ out, int N,
-                                                                      int D, int H) {
+                                                                      int D, int H, const int* __restrict__ tile_list,
+                                                                      int n_tiles) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int r0 = ((int)blockIdx.x * kUpdWaves + wave) * 16;
+  const int ti = (int)blockIdx.x * kUpdWaves + wave;
+  if (ti >= n_tiles) return;
+  const int r0 = (tile_list ? tile_list[ti] : ti) * 16;
   if (r0 >= N) return;
   const int i = lane & 15, kq = lane >> 4;
   const int row = r0 + i;
@@ -77,7 +80,9 @@ template <int T>
 __global__ __launch_bounds__(kUpdWaves * 64) void dense_update_stream_kernel(const float* __restrict__ in,
                                                                              const float* __restrict__ W,
                                                                              long long ldr, long long ldc,
-                                                                             float* __restrict__ out, int N, int D) {
+                                                                             float* __restrict__ out, int N, int D,
+                                                                             const int* __restrict__ tile_list,
+                                                                             int n_tiles) {
   extern __shared__ __attribute__((aligned(16))) float s_w[];  // [D][HS], HS = 16*T + 4 (row stride = 4 mod 8 words)
   constexpr int H = 16 * T;
   constexpr int HS = H + 4;
@@ -89,9 +94,8 @@ __global__ __launch_bounds__(kUpdWaves * 64) void dense_update_stream_kernel(con
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int i = lane & 15, kq = lane >> 4;
-  const int tiles = (N + 15) / 16;
-  for (int tile = (int)blockIdx.x * kUpdWaves + wave; tile < tiles; tile += (int)gridDim.x * kUpdWaves) {
-    const int r0 = tile * 16;
+  for (int ti = (int)blockIdx.x * kUpdWaves + wave; ti < n_tiles; ti += (int)gridDim.x * kUpdWaves) {
+    const int r0 = (tile_list ? tile_list[ti] : ti) * 16;
     const int row = r0 + i;
     const bool rok = row < N;
     const f32x4* arow = reinterpret_cast<const f32x4*>(in + (size_t)(rok ? row : 0) * (size_t)D) + kq;
@@ -132,13 +136,12 @@ __global__ __launch_bounds__(kUpdWaves * 64) void dense_update_stream_kernel(con
 
 template <int T>
 static hipError_t launch_stream(const float* in, const float* W, long long ldr, long long ldc, float* out, int N, int D,
-                                hipStream_t stream) {
+                                const int* tile_list, int n_tiles, hipStream_t stream) {
   const size_t lds = (size_t)D * (16 * T + 4) * sizeof(float);
-  const int tiles = (N + 15) / 16;
-  int grid = (tiles + kUpdWaves - 1) / kUpdWaves;
+  int grid = (n_tiles + kUpdWaves - 1) / kUpdWaves;
   if (grid > 1024) grid = 1024;  // W is staged once per workgroup: stride over the row tiles
   hipLaunchKernelGGL((dense_update_stream_kernel<T>), dim3(grid), dim3(kUpdWaves * 64), lds, stream, in, W, ldr, ldc,
-                     out, N, D);
+                     out, N, D, tile_list, n_tiles);
   return hipGetLastError();
 }
 
@@ -287,21 +290,27 @@ hipError_t launch_weight_grad(const float* A, long long lda, const float* B, lon
   return hipErrorInvalidValue;
 }
 
-hipError_t launch_dense_update(const float* in, const float* W, long long ldr, long long ldc, float* out, int N,
-                               int D, int H, hipStream_t stream) {
-  if (N <= 0 || H <= 0) return hipSuccess;
+bool dense_update_streams(const float* in, const float* out, int D, int H) {
   const bool aligned16 = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
-  if (aligned16 && D % 16 == 0 && H % 16 == 0 && H <= 64 && (size_t)D * (H + 4) * sizeof(float) <= 64 * 1024) {
+  return aligned16 && D % 16 == 0 && H % 16 == 0 && H <= 64 && (size_t)D * (H + 4) * sizeof(float) <= 64 * 1024;
+}
+
+hipError_t launch_dense_update(const float* in, const float* W, long long ldr, long long ldc, float* out, int N,
+                               int D, int H, const int* tile_list, int n_tiles, hipStream_t stream) {
+  if (N <= 0 || H <= 0) return hipSuccess;
+  if (!tile_list) n_tiles = (N + 15) / 16;
+  if (n_tiles <= 0) return hipSuccess;
+  if (dense_update_streams(in, out, D, H)) {
     switch (H / 16) {
-      case 1: return launch_stream<1>(in, W, ldr, ldc, out, N, D, stream);
-      case 2: return launch_stream<2>(in, W, ldr, ldc, out, N, D, stream);
-      case 3: return launch_stream<3>(in, W, ldr, ldc, out, N, D, stream);
-      default: return launch_stream<4>(in, W, ldr, ldc, out, N, D, stream);
+      case 1: return launch_stream<1>(in, W, ldr, ldc, out, N, D, tile_list, n_tiles, stream);
+      case 2: return launch_stream<2>(in, W, ldr, ldc, out, N, D, tile_list, n_tiles, stream);
+      case 3: return launch_stream<3>(in, W, ldr, ldc, out, N, D, tile_list, n_tiles, stream);
+      default: return launch_stream<4>(in, W, ldr, ldc, out, N, D, tile_list, n_tiles, stream);
     }
   }
-  const int rows_per_wg = 16 * kUpdWaves;
-  const int grid = (N + rows_per_wg - 1) / rows_per_wg;
-  hipLaunchKernelGGL(dense_update_kernel, dim3(grid), dim3(kUpdWaves * 64), 0, stream, in, W, ldr, ldc, out, N, D, H);
+  const int grid = (n_tiles + kUpdWaves - 1) / kUpdWaves;
+  hipLaunchKernelGGL(dense_update_kernel, dim3(grid), dim3(kUpdWaves * 64), 0, stream, in, W, ldr, ldc, out, N, D, H,
+                     tile_list, n_tiles);
   return hipGetLastError();
 }
 

@@ -24,7 +24,7 @@ __all__ = [
     "forward_fixed64_fused", "forward_final_fused", "forward_final_fused_64", "forward_GIN_final_fused", "backward",
     "backward_fixed32", "backward_fixed32_fused", "backward_final_fused", "backward_fixed64",
     "backward_fixed64_fused", "backward_final_fused_64", "backward_GIN_final_fused", "loi_reorder",
-    "apply_permutation", "weight_grad", "plan_header", "forward_rect", "forward_into", "wide_threshold", "workspace_bytes", "build_plan", "set_default_rule", "RULE_INTENDED", "RULE_INTENDED_GUARD",
+    "apply_permutation", "weight_grad", "plan_header", "forward_rect", "forward_into", "wide_threshold", "workspace_bytes", "fused_in_launch", "build_plan", "set_default_rule", "RULE_INTENDED", "RULE_INTENDED_GUARD",
     "RULE_AS_SHIPPED", "RULE_MI355X", "RULE_MI355X_WIDE", "mi355x_rule",
 ]
 
@@ -147,6 +147,13 @@ def workspace_bytes(row_nzr, embedding_dim):
     """Bytes of fp32 workspace a forward with this plan and width needs (partial sums of split rows); 0 without a plan."""
     h = plan_header(row_nzr)
     return int(lib().hcspmm_workspace_bytes(ctypes.byref(h), int(embedding_dim))) if h is not None else 0
+
+
+def fused_in_launch(row_nzr, embedding_dim, hidden_dim):
+    """True when forward_*_fused with this plan and shape updates its dense-tile windows inside the hybrid launch
+    (hcspmm_fused_in_launch, include/hcspmm.h)."""
+    h = plan_header(row_nzr)
+    return bool(h is not None and lib().hcspmm_fused_in_launch(ctypes.byref(h), int(embedding_dim), int(hidden_dim)))
 
 
 def _ptr(t):

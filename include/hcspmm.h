@@ -255,7 +255,18 @@ int32_t hcspmm_wide_threshold_typed(const hcspmm_plan_header* header_h, int embe
  * K.cu:596, _fixed64_fused :651, _final_fused :701, _final_fused_64 :759, _GIN_final_fused :810
  * (bindings B.cpp:310-498) and their kernels K.cu:1639-2770.
  * `out_d` may be a caller-owned buffer (forward_final_fused writes the caller's `output`).
+ *
+ * With a plan that has dense-tile windows, fp32, D and H multiples of 16 and H <= 64, those windows are updated
+ * INSIDE the hybrid launch: the aggregation runs with exchanged MFMA operands, which leaves each lane holding one
+ * row of the 16 x D tile in exactly the A-operand shape of the (tile x weights) MFMAs, so the tile goes from the
+ * accumulators straight into the update (W staged in LDS) without touching LDS or HBM -- the reference keeps it in
+ * shared memory (K.cu:1807-1837).  The windows on the sparse-row path, whose rows are spread over unrelated waves
+ * by the length-sorted task schedule, are then multiplied by a second launch restricted to them (the plan lists
+ * them: off_sparse_windows).  Otherwise: the hybrid launch + one update launch over all rows.
+ * hcspmm_fused_in_launch() tells which form a (plan, D, H) gets (1 = dense windows update in the hybrid launch);
+ * HCSPMM_FUSED_SINGLE_LAUNCH=0 in the environment forces the two-launch form.
  * ---------------------------------------------------------------------------------------- */
+int hcspmm_fused_in_launch(const hcspmm_plan_header* header_h, int embedding_dim, int hidden_dim);
 int hcspmm_forward_fused(const float* X_d, float* out_d, float* out2_d, const float* weights_d,
                          int64_t weights_ld_row, int64_t weights_ld_col, int hidden_dim,
                          const int32_t* row_pointers_d, const int32_t* column_index_d,

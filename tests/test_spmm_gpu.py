@@ -339,20 +339,55 @@ def test_tiny_tasks_and_tiny_segments(oracle_mod, dev, fe, D):
     assert np.array_equal(g.forward(_t(Xi, dev)).cpu().numpy(), oracle_mod.spmm_f32(rp, col, Xi))
 
 
-@pytest.mark.parametrize("D,H", [(32, 32), (64, 64), (96, 22), (32, 7), (16, 40)])
-def test_fused_variants(oracle_mod, dev, fe, D, H):
-    rp, col = graphs.powerlaw_graph(1200, 9000, seed=6)
-    g = Graph(rp, col, dev, fe=fe)
+_FUSED_GRAPHS = [
+    ("powerlaw", lambda: graphs.powerlaw_graph(1200, 9000, seed=6)),
+    ("planted_ragged", lambda: graphs.planted_dense_graph(1500 - 7, seed=14)),  # compact dense windows, N % 16 != 0
+    ("wide_windows", lambda: _wide_window_graph()),                             # K = 48..130: double records + regular packs
+]
+
+
+def _wide_window_graph(seed=11):
+    rng = np.random.default_rng(seed)
+    Ks = [48, 56, 64, 80, 88, 96, 130, 24, 8, 130, 72, 41]
+    N = 16 * len(Ks)
+    rows, cols = [], []
+    for w, K in enumerate(Ks):
+        cset = np.sort(rng.choice(N, K, replace=False))
+        m = rng.random((16, K)) < 0.5
+        m[rng.integers(0, 16, K), np.arange(K)] = True
+        r, k = np.nonzero(m)
+        rows.append(16 * w + r)
+        cols.append(cset[k])
+    return graphs._to_csr(np.concatenate(rows), np.concatenate(cols), N)
+
+
+@pytest.mark.parametrize("D,H", [(32, 32), (64, 64), (96, 22), (32, 7), (16, 40), (128, 32), (48, 16), (256, 32), (16, 16),
+                                 (96, 16), (128, 64), (64, 32), (32, 16), (512, 32)])
+@pytest.mark.parametrize("gname,gen", _FUSED_GRAPHS, ids=[g[0] for g in _FUSED_GRAPHS])
+def test_fused_variants(oracle_mod, dev, fe, gname, gen, D, H):
+    """out2 = A*X, out = out2 * W for every fused name of the reference's module.  With dense-tile windows and D, H
+    multiples of 16 (H <= 64) those windows are updated inside the hybrid launch (transposed-tile MFMA chain); the
+    wide_windows graph is forced all-dense so that every record kind takes that path."""
+    rp, col = gen()
+    g = Graph(rp, col, dev, fe=fe, force_type=1 if gname == "wide_windows" else None)
+    in_launch = hcspmm.fused_in_launch(g.row_nzr, D, H)
+    # in the launch: fp32, D a multiple of 16 from 32 up, H = 16 or 32 (output tiles held in registers), W fits the LDS staging area
+    assert in_launch == (g.header().n_dense > 0 and D % 16 == 0 and D >= 32 and H in (16, 32) and D * (H + 4) * 4 <= 64 * 1024)
+    if gname != "powerlaw":
+        assert g.header().n_dense > 0
     rng = np.random.default_rng(7)
     X = rng.standard_normal((g.N, D)).astype(np.float32)
     W = rng.standard_normal((D, H)).astype(np.float32)
     want_out, want_out2 = oracle_mod.spmm_fused_f32(rp, col, X, W)
     Xd, Wd = _t(X, dev), _t(W, dev)
+    Z_plain = g.forward(Xd)
     scale = oracle_mod.spmm_f64(rp, col, X, absolute=True) @ np.abs(W).astype(np.float64)  # sum|x_j| . |W|
     for name in frontends.FUSED_NAMES:
         out, out2 = getattr(fe, name)(Xd, *g.args(), Wd)
+        assert torch.equal(out2, Z_plain), name  # the aggregate has the unfused operator's bits, whichever form ran
         assert oracle_mod.check_spmm(out2.cpu().numpy(), rp, col, X)[0]
-        assert np.all(np.abs(out.cpu().numpy().astype(np.float64) - want_out) <= 1e-5 * scale + 1e-30)
+        assert np.all(np.abs(out.cpu().numpy().astype(np.float64) - want_out) <= 1e-5 * scale + 1e-30), name
+        assert torch.equal(out, getattr(fe, name)(Xd, *g.args(), Wd)[0])  # deterministic
     # transposed (non-contiguous) weights, as the reference's backward passes them (GNN_model.py:98,120)
     Wt_d = _t(np.ascontiguousarray(W.T), dev).transpose(0, 1)
     assert not Wt_d.is_contiguous()
@@ -364,6 +399,12 @@ def test_fused_variants(oracle_mod, dev, fe, D, H):
         out, out2 = getattr(fe, name)(Xd, *g.args(), Wd, buf)
         assert out.data_ptr() == buf.data_ptr()
         assert np.all(np.abs(buf.cpu().numpy().astype(np.float64) - want_out) <= 1e-5 * scale + 1e-30)
+    # integer-valued X and W: every product and partial sum is exact, so out must be EXACT in either form
+    Xi = (np.arange(g.N, dtype=np.float32)[:, None] % 7 + np.arange(D, dtype=np.float32)[None, :] % 3)
+    Wi = ((np.arange(D)[:, None] + 2 * np.arange(H)[None, :]) % 5 - 2).astype(np.float32)
+    out, out2 = fe.forward_fixed32_fused(_t(Xi, dev), *g.args(), _t(Wi, dev))
+    zi = oracle_mod.spmm_f32(rp, col, Xi)
+    assert np.array_equal(out2.cpu().numpy(), zi) and np.array_equal(out.cpu().numpy(), zi.astype(np.float64) @ Wi.astype(np.float64))
 
 
 @pytest.mark.parametrize("N,D,H", [(70001, 96, 32), (5000, 32, 32), (9999, 32, 22), (4097, 64, 64), (300, 7, 3),

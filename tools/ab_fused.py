@@ -1,0 +1,90 @@
+"""A/B of the fused aggregate+update operators (reference hybrid_all_kernel.cu:1639-1848 etc.):
+  two-launch form  : hybrid SpMM launch (writes out2 = A*X) + streaming MFMA update launch over ALL rows;
+  in-launch form   : dense-tile windows multiply their tile by W inside the hybrid launch (tile kept in the MFMA
+                     accumulators), update launch restricted to the sparse-row windows.
+Each form runs in its own process (the switch HCSPMM_FUSED_SINGLE_LAUNCH is read once per process).
+
+  python tools/ab_fused.py            -> prints one table; the builder keeps it as profiles/r02/ab_fused.log
+"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "hc-spmm_amd")]
+
+WORKLOADS = ["dense", "yh_like", "c5_share", "alldense", "reddit"]
+SHAPES = [(32, 32), (128, 32), (64, 64)]
+
+
+def child():
+    import numpy as np
+    import torch
+    import bench
+    import hcspmm
+    dev = torch.device("cuda:0")
+
+    def timeit(fn, n=50):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(n):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / n * 1e3
+    out = {}
+    for wl in sys.argv[2].split(","):
+        n_local, e_local, _, vw, _ = bench.WORKLOADS[wl]
+        if vw != 1:  # the fused operators are square (out2 has the graph's rows): use the block's own columns only
+            from hcspmm import graphs
+            rp, col = graphs.planted_powerlaw_block(n_local, n_local, e_local, seed=3)
+        else:
+            rp, col = bench.make_local_block(wl, n_local, e_local, 1, 0)
+        N, E = len(rp) - 1, len(col)
+        rp_d, col_d = torch.from_numpy(rp).to(dev), torch.from_numpy(col).to(dev)
+        outs = hcspmm.preprocess(col_d, rp_d, N, E, (N + 15) // 16)
+        h = hcspmm.plan_header(outs[4])
+        for D, H in SHAPES:
+            X, W = torch.randn(N, D, device=dev), torch.randn(D, H, device=dev)
+            a = (rp_d, col_d, *outs)
+            t_sp = timeit(lambda: hcspmm.forward(X, *a))
+            t_fu = timeit(lambda: hcspmm.forward_fixed32_fused(X, *a, W))
+            out["%s D=%d H=%d" % (wl, D, H)] = {"spmm_us": t_sp, "fused_us": t_fu, "dense_windows": h.n_dense,
+                                                 "sparse_windows": h.n_sparse_windows,
+                                                 "in_launch": hcspmm.fused_in_launch(outs[4], D, H)}
+        del outs, rp_d, col_d
+        torch.cuda.empty_cache()
+    print("RESULT " + json.dumps(out))
+
+
+def main():
+    wls = sys.argv[1] if len(sys.argv) > 1 else ",".join(WORKLOADS)
+    res = {}
+    for mode in ("0", "1"):
+        env = dict(os.environ, HCSPMM_FUSED_SINGLE_LAUNCH=mode)
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", wls], env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True)
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")]
+        if not line:
+            print(p.stdout[-2000:], p.stderr[-2000:])
+            sys.exit(1)
+        res[mode] = json.loads(line[0][7:])
+    print("fused aggregate+update, one MI355X; times in us per call (50 calls after 5 warm-ups, HIP events)")
+    print("%-26s %9s %9s | %12s %12s %8s | %s" % ("workload / shape", "dense win", "sparse win", "two launches", "in-launch", "gain",
+                                                 "SpMM alone"))
+    for k in res["0"]:
+        a, b = res["0"][k], res["1"][k]
+        print("%-26s %9d %9d | %12.1f %12.1f %7.1f%% | %10.1f   %s" % (k, a["dense_windows"], a["sparse_windows"], a["fused_us"],
+                                                                      b["fused_us"], 100.0 * (a["fused_us"] - b["fused_us"]) / a["fused_us"],
+                                                                      a["spmm_us"], "" if b["in_launch"] else "(shape/plan outside the in-launch form)"))
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--child":
+        child()
+    else:
+        main()

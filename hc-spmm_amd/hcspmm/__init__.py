@@ -449,7 +449,9 @@ backward_GIN_final_fused = forward_GIN_final_fused
 
 def loi_reorder(row_pointers, column_index, variant="new_direct"):
     """LOI layout reorder (LOI.cpp:660-805 + main's output order) -> (perm[N], group_sizes).
-    variant "new" = reorder_plus_new (LOI.cpp:505-658, symmetric-graph form)."""
+    variant "new" = reorder_plus_new (LOI.cpp:505-658, symmetric-graph form); "plus_direct" / "plus" = the windowed
+    variants reorder_plus_direct / reorder_plus (LOI.cpp:286-484 / :98-284; defined for graphs of at least 50 rows
+    without empty rows -- other inputs raise); a HCSPMM_LOI_* number is accepted as well."""
     L = lib()
     rp = _i32_host(row_pointers)
     col = _i32_host(column_index)
@@ -457,8 +459,8 @@ def loi_reorder(row_pointers, column_index, variant="new_direct"):
     perm = torch.empty(N, dtype=torch.int32)
     gs = torch.empty(max(N, 1), dtype=torch.int32)
     ng = ctypes.c_int64(0)
-    check(L.hcspmm_loi_reorder_variant(_ptr(rp), _ptr(col), N, E, {"new_direct": 0, "new": 1}[variant], _ptr(perm), _ptr(gs),
-                                       ctypes.byref(ng)))
+    v = variant if isinstance(variant, int) else {"new_direct": 0, "new": 1, "plus_direct": 2, "plus": 3}[variant]
+    check(L.hcspmm_loi_reorder_variant(_ptr(rp), _ptr(col), N, E, v, _ptr(perm), _ptr(gs), ctypes.byref(ng)))
     return perm, gs[:ng.value].clone()
 
 

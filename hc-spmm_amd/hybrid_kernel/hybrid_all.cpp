@@ -435,7 +435,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     check_rc(hcspmm_loi_reorder_variant(rp.data_ptr<int>(), iptr(col), N, E, variant, mptr(perm), sizes.data_ptr<int>(), &ng),
              "loi_reorder");
     return std::vector<torch::Tensor>{perm, sizes.slice(0, 0, ng).clone()};
-  }, "-> [perm (old vertex id at each new position), group sizes]; variant 0 = reorder_plus_new_direct, 1 = reorder_plus_new",
+  }, "-> [perm (old vertex id at each new position), group sizes]; variant 0 = reorder_plus_new_direct, 1 = reorder_plus_new, "
+     "2 / 3 = the windowed reorder_plus_direct / reorder_plus (>= 50 rows, no empty rows)",
         pybind11::arg("row_pointers"), pybind11::arg("column_index"), pybind11::arg("variant") = 0);
   m.def("apply_permutation", [](torch::Tensor row_pointers, torch::Tensor column_index, torch::Tensor perm) {
     auto rp = row_pointers.to(torch::kCPU, torch::kInt).contiguous();

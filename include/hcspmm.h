@@ -305,6 +305,13 @@ int hcspmm_loi_reorder(const int32_t* row_pointers_h, const int32_t* column_inde
  * (it assumes a symmetric graph); on symmetric input both variants give the same order. */
 #define HCSPMM_LOI_NEW_DIRECT 0
 #define HCSPMM_LOI_NEW 1
+/* The reference's two windowed variants (not called by its main): reorder_plus_direct LOI.cpp:286-484 and
+ * reorder_plus LOI.cpp:98-284 -- rows ordered by their smallest column id, a group grown from the next 300 rows of
+ * that order.  Bit-identical to the reference compiled with this image's libstdc++ (its row order comes from a
+ * non-stable std::sort) on the inputs where the reference is defined: at least 50 rows, no row without entries,
+ * columns strictly ascending within a row; anything else is HCSPMM_EINVAL (the reference reads out of bounds). */
+#define HCSPMM_LOI_WINDOWED_DIRECT 2
+#define HCSPMM_LOI_WINDOWED 3
 int hcspmm_loi_reorder_variant(const int32_t* row_pointers_h, const int32_t* column_index_h, int64_t num_nodes,
                                int64_t num_edges, int variant, int32_t* perm_out_h, int32_t* group_sizes_out_h,
                                int64_t* n_groups_out);

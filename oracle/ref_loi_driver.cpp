@@ -16,7 +16,12 @@
 #include <cstring>
 #include <vector>
 
-// Signatures as declared in /root/reference/LOI.cpp:507 and :660.
+// Signatures as declared in /root/reference/LOI.cpp:98, :286, :507 and :660.
+void reorder_plus(std::vector<int>& row_id, std::vector<int>& col_id, int node_num, std::vector<std::vector<int>>& res,
+                  std::vector<bool>& visit);
+void reorder_plus_direct(std::vector<int>& row_id, std::vector<int>& col_id, int node_num,
+                         std::vector<std::vector<int>>& res, std::vector<bool>& visit, std::vector<int>& row_id_in,
+                         std::vector<int>& col_id_in);
 void reorder_plus_new(std::vector<int>& row_id, std::vector<int>& col_id, int node_num,
                       std::vector<std::vector<int>>& res, std::vector<bool>& visit);
 void reorder_plus_new_direct(std::vector<int>& row_id, std::vector<int>& col_id, int node_num,
@@ -25,7 +30,7 @@ void reorder_plus_new_direct(std::vector<int>& row_id, std::vector<int>& col_id,
 
 int main(int argc, char** argv) {
   if (argc < 4) {
-    std::fprintf(stderr, "usage: %s <new|new_direct> <in.bin> <out.bin>\n", argv[0]);
+    std::fprintf(stderr, "usage: %s <new|new_direct|plus|plus_direct> <in.bin> <out.bin>\n", argv[0]);
     return 2;
   }
   const char* variant = argv[1];
@@ -55,6 +60,8 @@ int main(int argc, char** argv) {
   FILE* quiet = std::freopen("/dev/null", "w", stdout);
   (void)quiet;
   if (!std::strcmp(variant, "new")) reorder_plus_new(row_id, col_id, (int)N, res, visit);
+  else if (!std::strcmp(variant, "plus")) reorder_plus(row_id, col_id, (int)N, res, visit);  // windowed (VW = 300)
+  else if (!std::strcmp(variant, "plus_direct")) reorder_plus_direct(row_id, col_id, (int)N, res, visit, row_id_in, col_id_in);
   else reorder_plus_new_direct(row_id, col_id, (int)N, res, visit, row_id_in, col_id_in);
 
   FILE* fo = std::fopen(argv[3], "wb");

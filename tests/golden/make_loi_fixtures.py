@@ -3,8 +3,11 @@
 Each fixture = a small seeded CSR graph + the vertex order and group sizes that the REFERENCE's
 own LOI.cpp (compiled from /root/reference by `make -C oracle ref`, driven by
 oracle/ref_loi_driver.cpp) produces for it with reorder_plus_new_direct, the variant its main
-calls (LOI.cpp:848).  The fixtures are data (inputs + expected outputs); no reference source
-travels.  Usage: python tests/golden/make_loi_fixtures.py
+calls (LOI.cpp:848).  The loi_win_*.npz fixtures pin the two WINDOWED variants reorder_plus_direct / reorder_plus
+(LOI.cpp:286-484 / :98-284) on graphs inside the domain where the reference is defined (>= 50 rows, no row without
+entries); their row order comes from a non-stable std::sort, so they are tied to this container's libstdc++.
+The fixtures are data (inputs + expected outputs); no reference source travels.
+Usage: python tests/golden/make_loi_fixtures.py
 """
 import os
 import struct
@@ -64,6 +67,32 @@ def cases():
     yield "tiny_path_5", (np.array([0, 1, 3, 5, 7, 8], np.int32), np.array([1, 0, 2, 1, 3, 2, 4, 3], np.int32))
 
 
+def _fill_empty_rows(rp, col, seed):
+    """Give every row without entries one entry (the windowed variants read out of bounds on empty rows)."""
+    N = len(rp) - 1
+    rng = np.random.default_rng(seed)
+    deg = np.diff(rp)
+    rows = np.repeat(np.arange(N), deg)
+    empty = np.nonzero(deg == 0)[0]
+    r = np.concatenate([rows, empty]).astype(np.int64)
+    c = np.concatenate([col, (empty + 1 + rng.integers(0, N - 1, len(empty))) % N]).astype(np.int64)
+    rp2, col2 = graphs._to_csr(r, c, N)
+    assert np.diff(rp2).min() > 0
+    return rp2, col2
+
+
+def windowed_cases():
+    yield "uniform_64", _fill_empty_rows(*graphs.uniform_graph(64, 300, seed=11), seed=1)            # barely above the 50-row floor
+    yield "powerlaw_777", _fill_empty_rows(*graphs.powerlaw_graph(777, 6000, seed=12), seed=2)       # N % 16 != 0, three windows of 300
+    yield "planted_1200", _fill_empty_rows(*graphs.planted_dense_graph(1200, seed=13), seed=3)
+    # many rows share their smallest column id: the order of equal keys is whatever the non-stable sort leaves
+    rng = np.random.default_rng(14)
+    N = 400
+    rows = np.repeat(np.arange(N), 4)
+    cols = np.concatenate([np.stack([rng.integers(0, 6, N), rng.integers(6, N, N), rng.integers(6, N, N), rng.integers(6, N, N)], 1).ravel()])
+    yield "ties_400", graphs._to_csr(rows.astype(np.int64), cols.astype(np.int64), N)
+
+
 if __name__ == "__main__":
     if not os.path.exists(REF_BIN):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
@@ -76,3 +105,12 @@ if __name__ == "__main__":
                             group_sizes=sizes, group_members=members, order=order,
                             group_sizes_new=sizes_n, group_members_new=members_n, order_new=order_n)
         print(name, "N", len(rp) - 1, "E", len(col), "groups", len(sizes), "full", int((sizes == 16).sum()))
+    for name, (rp, col) in windowed_cases():
+        assert np.diff(rp).min() > 0 and len(rp) - 1 >= 50
+        sizes_d, members_d, order_d = run_ref(rp, col, "plus_direct")
+        sizes_p, members_p, order_p = run_ref(rp, col, "plus")
+        assert sorted(order_d.tolist()) == list(range(len(rp) - 1)) and sorted(order_p.tolist()) == list(range(len(rp) - 1)), name
+        np.savez_compressed(os.path.join(out_dir, "loi_win_%s.npz" % name), row_pointers=rp, column_index=col,
+                            group_sizes_plus_direct=sizes_d, group_members_plus_direct=members_d, order_plus_direct=order_d,
+                            group_sizes_plus=sizes_p, group_members_plus=members_p, order_plus=order_p)
+        print("windowed", name, "N", len(rp) - 1, "E", len(col), "groups", len(sizes_d), len(sizes_p), "full", int((sizes_d == 16).sum()))

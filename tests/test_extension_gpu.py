@@ -114,7 +114,15 @@ def test_extension_host_utilities(HCSPMM):
     """LOI reorder / permutation / plan_info through the compiled module (host side, no GPU needed)."""
     import glob
     gold = os.path.join(ROOT, "tests", "golden")
+    for path in sorted(glob.glob(os.path.join(gold, "loi_win_*.npz"))):  # the windowed variants (2 / 3)
+        g = np.load(path)
+        rp, col = torch.from_numpy(g["row_pointers"]), torch.from_numpy(g["column_index"])
+        for variant, key in ((2, "plus_direct"), (3, "plus")):
+            perm, sizes = HCSPMM.loi_reorder(rp, col, variant)
+            assert np.array_equal(perm.numpy(), g["order_" + key]) and np.array_equal(sizes.numpy(), g["group_sizes_" + key])
     for path in sorted(glob.glob(os.path.join(gold, "loi_*.npz"))):
+        if "loi_win_" in path:
+            continue
         g = np.load(path)
         rp, col = torch.from_numpy(g["row_pointers"]), torch.from_numpy(g["column_index"])
         perm, sizes = HCSPMM.loi_reorder(rp, col)

@@ -406,7 +406,42 @@ def capi_fingerprint_reference(rp, col):
         return int((t_rp.sum(dtype=np.uint64) + t_col.sum(dtype=np.uint64) + seed[0]) & M)
 
 
-@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "loi_*.npz"))))
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "loi_win_*.npz"))))
+def test_windowed_loi_reorder_matches_reference_golden(path):
+    """reorder_plus_direct / reorder_plus (LOI.cpp:286-484 / :98-284, vertex window 300) against permutations produced
+    by the reference's own LOI.cpp compiled in the authoring container (tests/golden/make_loi_fixtures.py)."""
+    g = np.load(path)
+    for variant in ("plus_direct", "plus"):
+        perm, sizes = hcspmm.loi_reorder(_t(g["row_pointers"]), _t(g["column_index"]), variant=variant)
+        assert np.array_equal(sizes.numpy(), g["group_sizes_" + variant]), variant
+        assert np.array_equal(perm.numpy(), g["order_" + variant]), variant
+        assert sorted(perm.tolist()) == list(range(len(g["row_pointers"]) - 1))
+
+
+def test_windowed_loi_reorder_refuses_inputs_outside_the_reference_domain(capi):
+    """Fewer than 50 rows (the reference's `size() - 50` underflows, LOI.cpp:333), a row without entries (its window
+    bound reads past the row-order array, LOI.cpp:362) or an unsorted row (its residual merge assumes ascending
+    columns): HCSPMM_EINVAL instead of reproducing undefined behaviour."""
+    rp, col = graphs.uniform_graph(49, 300, seed=1)
+    for variant in ("plus_direct", "plus"):
+        with pytest.raises(RuntimeError, match="invalid argument"):
+            hcspmm.loi_reorder(_t(rp), _t(col), variant=variant)
+    rp, col = np.load(os.path.join(GOLD, "loi_win_uniform_64.npz"))["row_pointers"], np.load(os.path.join(GOLD, "loi_win_uniform_64.npz"))["column_index"]
+    hole = rp.copy()
+    hole[6:] -= rp[6] - rp[5]  # row 5 loses its entries
+    col_hole = np.concatenate([col[:rp[5]], col[rp[6]:]])
+    with pytest.raises(RuntimeError, match="invalid argument"):
+        hcspmm.loi_reorder(_t(hole), _t(col_hole), variant="plus_direct")
+    r = int(np.argmax(np.diff(rp) >= 2))
+    swapped = col.copy()
+    swapped[rp[r]], swapped[rp[r] + 1] = col[rp[r] + 1], col[rp[r]]
+    with pytest.raises(RuntimeError, match="invalid argument"):
+        hcspmm.loi_reorder(_t(rp), _t(swapped), variant="plus")
+    with pytest.raises(RuntimeError, match="invalid argument"):
+        hcspmm.loi_reorder(_t(rp), _t(col), variant=7)
+
+
+@pytest.mark.parametrize("path", sorted(p for p in glob.glob(os.path.join(GOLD, "loi_*.npz")) if "loi_win_" not in p))
 def test_loi_reorder_matches_reference_golden(path):
     g = np.load(path)
     perm, sizes = hcspmm.loi_reorder(_t(g["row_pointers"]), _t(g["column_index"]))
@@ -425,10 +460,7 @@ def test_loi_reorder_matches_compiled_reference_on_random_graphs():
     if not os.path.exists(ref_bin):
         pytest.skip("oracle/_ref/loi_ref not built (no /root/reference here)")
     sys.path.insert(0, GOLD)
-    try:
-        from make_loi_fixtures import run_ref
-    finally:
-        sys.path.pop(0)
+    from make_loi_fixtures import run_ref
     rng = np.random.default_rng(77)
     for i in range(8):
         N = int(rng.integers(100, 4000))
@@ -443,6 +475,16 @@ def test_loi_reorder_matches_compiled_reference_on_random_graphs():
             sizes, _, order = run_ref(rp, col, variant)
             perm, gs = hcspmm.loi_reorder(_t(rp), _t(col), variant=variant)
             assert np.array_equal(perm.numpy(), order) and np.array_equal(gs.numpy(), sizes), (i, variant)
+    # the windowed variants, on graphs inside the reference's defined domain (no row without entries)
+    from make_loi_fixtures import _fill_empty_rows
+    for i in range(12):
+        N = int(rng.choice([50, 51, 64, 299, 300, 301, 650, 1500]))
+        gen = (graphs.uniform_graph, graphs.powerlaw_graph)[i % 2]
+        rp, col = _fill_empty_rows(*gen(N, N * int(rng.integers(2, 9)), seed=200 + i), seed=i)
+        for variant in ("plus_direct", "plus"):
+            sizes, _, order = run_ref(rp, col, variant)
+            perm, gs = hcspmm.loi_reorder(_t(rp), _t(col), variant=variant)
+            assert np.array_equal(perm.numpy(), order) and np.array_equal(gs.numpy(), sizes), (i, N, variant)
 
 
 def test_loi_reorder_matches_oracle_on_larger_graph():

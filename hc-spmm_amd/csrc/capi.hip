@@ -132,6 +132,35 @@ __global__ __launch_bounds__(256) void fingerprint_kernel(const int32_t* __restr
 }
 }  // namespace
 
+namespace {
+// edgeToRow[e] = largest r with rowptr[r] <= e (rows without entries never win: the search looks for the LAST such row)
+__global__ __launch_bounds__(256) void edge_to_row_kernel(const int32_t* __restrict__ rowptr, int N, long long E,
+                                                          int32_t* __restrict__ e2r) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += stride) {
+    int lo = 0, hi = N;  // invariant: rowptr[lo] <= e < rowptr[hi]
+    while (hi - lo > 1) {
+      const int mid = lo + ((hi - lo) >> 1);
+      if ((long long)rowptr[mid] <= e) lo = mid;
+      else hi = mid;
+    }
+    e2r[e] = lo;
+  }
+}
+}  // namespace
+
+extern "C" int hcspmm_edge_to_row_device(const int32_t* rowptr, int64_t N, int64_t E, int32_t* e2r, void* stream_v) {
+  if (N < 0 || E < 0 || !rowptr || (E > 0 && !e2r)) return HCSPMM_EINVAL;
+  if (N > INT32_MAX - 16 || E > INT32_MAX) return HCSPMM_ERANGE;
+  if (E == 0) return HCSPMM_OK;
+  long long blocks = (E + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(edge_to_row_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_v), rowptr,
+                     (int)N, (long long)E, e2r);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? HCSPMM_OK : fail_hip(e);
+}
+
 extern "C" int hcspmm_graph_fingerprint_device(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E,
                                                uint64_t* out_d, void* stream_v) {
   if (!rowptr || !out_d || N < 0 || E < 0 || (E > 0 && !col)) return HCSPMM_EINVAL;

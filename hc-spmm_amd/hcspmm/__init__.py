@@ -200,24 +200,30 @@ def preprocess(column_index, row_pointers, num_nodes, num_edges, num_row_windows
     ht = torch.empty(W, dtype=torch.int32)
     e2c = torch.empty(E, dtype=torch.int32)
     on_gpu = dev.type == "cuda"
-    # edgeToRow is the plain CSR row expansion: made on the device when the graph lives there
-    e2r = None if on_gpu else torch.empty(E, dtype=torch.int32)
+    # edgeToRow is the plain CSR row expansion: made on the device when the graph lives there -- fill_edgeToRow
+    # (K.cu:314-337) as one small HIP kernel of the library, enqueued now so that it runs under the host passes below
+    e2r = None
+    if on_gpu:
+        e2r = torch.empty(E, dtype=torch.int32, device=dev)
+        rp_dev = row_pointers.to(device=dev, dtype=torch.int32).contiguous()  # (no copy when it already is)
+        with torch.cuda.device(dev):
+            check(L.hcspmm_edge_to_row_device(_ptr(rp_dev), N, E, _ptr(e2r),
+                                              ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    e2r_h = None if on_gpu else torch.empty(E, dtype=torch.int32)
     if rule == "mi355x":
         if dim is None:
             raise RuntimeError('preprocess: rule="mi355x" needs dim= (the embedding width)')
         rule = mi355x_rule(dim)
     r = _DEFAULT_RULE if rule is None else int(rule)
     M = N if num_columns is None else int(num_columns)
-    check(L.hcspmm_preprocess_host(_ptr(rp_h), _ptr(col_h), N, E, M, r, 0, _ptr(bp), _ptr(e2c), _ptr(e2r), _ptr(ht)))
+    check(L.hcspmm_preprocess_host(_ptr(rp_h), _ptr(col_h), N, E, M, r, 0, _ptr(bp), _ptr(e2c), _ptr(e2r_h), _ptr(ht)))
+    if not on_gpu:
+        e2r = e2r_h
     words = ctypes.c_int64(0)
     check(L.hcspmm_plan_words(_ptr(rp_h), N, E, _ptr(bp), _ptr(ht), ctypes.byref(_PLAN_PARAMS), ctypes.byref(words)))
     plan = torch.empty(max(int(words.value), Header.WORDS), dtype=torch.int32)
     check(L.hcspmm_plan_build(_ptr(rp_h), _ptr(col_h), N, E, M, _ptr(bp), _ptr(e2c), _ptr(ht),
                               ctypes.byref(_PLAN_PARAMS), _ptr(plan), plan.numel()))
-    if on_gpu:
-        rp_dev = row_pointers.to(device=dev, dtype=torch.int64)
-        e2r = torch.repeat_interleave(torch.arange(N, dtype=torch.int32, device=dev), rp_dev[1:] - rp_dev[:-1],
-                                      output_size=E)
     h = Header.from_buffer_copy(plan[:Header.WORDS].numpy().tobytes())
     outs = [t.to(dev) for t in (bp, e2c, e2r, ht, plan)]  # .to() is a no-op for the device-made e2r
     _register(outs[4], h, row_pointers, column_index)

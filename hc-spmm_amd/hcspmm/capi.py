@@ -47,6 +47,7 @@ SYMBOLS = {
     "hcspmm_abi_version": (_int, []),
     "hcspmm_last_hip_error": (_int, []),
     "hcspmm_preprocess_host": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _int, _vp, _vp, _vp, _vp]),
+    "hcspmm_edge_to_row_device": (_int, [_vp, _i64, _i64, _vp, _vp]),
     "hcspmm_plan_words": (_int, [_vp, _i64, _i64, _vp, _vp, _pp, ctypes.POINTER(_i64)]),
     "hcspmm_plan_build": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _pp, _vp, _i64]),
     "hcspmm_plan_check": (_int, [_hp, _i64, _i64, _i64]),

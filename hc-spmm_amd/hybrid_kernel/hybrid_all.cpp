@@ -268,10 +268,13 @@ std::vector<torch::Tensor> preprocess(torch::Tensor edgeList_tensor, torch::Tens
   // edgeToRow is the plain CSR row expansion (reference fill_edgeToRow, K.cu:314-326): made on the
   // device when the graph lives there, so 4*E bytes skip the host round trip
   torch::Tensor e2r;
-  if (dev.is_cuda()) {
-    auto rp64 = nodePointer_tensor.to(dev, torch::kLong);
-    e2r = torch::repeat_interleave(torch::arange(N, torch::TensorOptions().dtype(torch::kInt).device(dev)),
-                                   rp64.slice(0, 1, N + 1) - rp64.slice(0, 0, N), /*dim=*/c10::nullopt, /*output_size=*/E);
+  if (dev.is_cuda()) {  // one small HIP kernel of the library, enqueued before (and running under) the host passes
+    e2r = torch::empty({E}, opts.device(dev));
+    auto rp_dev = nodePointer_tensor.to(dev, torch::kInt).contiguous();
+    const c10::DeviceGuard guard(dev);
+    check_rc(hcspmm_edge_to_row_device(rp_dev.data_ptr<int>(), N, E, mptr(e2r),
+                                       (void*)c10::hip::getCurrentHIPStream(dev.index()).stream()),
+             "preprocess(edgeToRow)");
   } else {
     e2r = torch::empty({E}, opts);
   }

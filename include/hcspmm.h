@@ -75,6 +75,13 @@ int hcspmm_preprocess_host(const int32_t* row_pointers_h, const int32_t* column_
                            int32_t* blockPartition_h, int32_t* edgeToColumn_h, int32_t* edgeToRow_h,
                            int32_t* hybrid_type_h);
 
+/* edgeToRow on the device: edgeToRow_d[e] = the row that owns stored entry e (the plain CSR row expansion).  Replaces
+ * fill_edgeToRow K.cu:314-337 for callers whose graph already lives in HBM (hcspmm_preprocess_host then gets
+ * edgeToRow_h = NULL): one thread per entry, a binary search in row_pointers (which sits in L2).  Rows without
+ * entries are skipped correctly.  Asynchronous on `stream`. */
+int hcspmm_edge_to_row_device(const int32_t* row_pointers_d, int64_t num_nodes, int64_t num_edges, int32_t* edgeToRow_d,
+                              void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Launch plan (host build, device resident).  New on MI355X: the reference branches per thread
  * block on hybrid_type (K.cu:960,1039) with one block per window; here the host turns the

@@ -173,6 +173,16 @@ int main() {
                                stream) != HCSPMM_EINVAL)
       return 13;
   }
+  // edgeToRow made on the device (fill_edgeToRow's counterpart) equals the host pass's
+  {
+    int32_t* e2r2_d = nullptr;
+    HIP_OK(hipMalloc(&e2r2_d, sizeof(int32_t) * (size_t)E));
+    HC_OK(hcspmm_edge_to_row_device(rp_d, N, E, e2r2_d, (void*)stream));
+    std::vector<int32_t> e2r2((size_t)E);
+    HIP_OK(hipMemcpyAsync(e2r2.data(), e2r2_d, sizeof(int32_t) * (size_t)E, hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    if (e2r2 != e2r) return 15;
+  }
   // the device fingerprint of the uploaded graph equals the host one stored in the plan header
   {
     uint64_t host_fp = 0, dev_fp = 0, *fp_d = nullptr;

@@ -332,11 +332,35 @@ def run_case(fe, dev, workload, D, rp, col, n_local, world, rank, vworld, steps,
     sync_all()
     elapsed = time.perf_counter() - t0
     kern_ms = float(np.sum([s.elapsed_time(e) for s, e in ev_pairs])) / steps if ev_pairs else float("nan")
+    graph_ms = None
+    if world == 1 and E <= 2_000_000:
+        # a launch-bound workload (Cora-scale: the kernel is a few microseconds, a Python call several times that): the
+        # same steps captured in a HIP graph -- the operator neither synchronises nor allocates -- and replayed
+        try:
+            reps = 50
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(gr, stream=side):
+                    for _ in range(reps):
+                        for p in range(op.n_panels):
+                            fe.forward_into(op.X_pm[p], op.Z_pm[p], graph_args, op.workspace)
+            gr.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                gr.replay()
+            torch.cuda.synchronize()
+            graph_ms = (time.perf_counter() - t0) / (10 * reps) * 1e3
+        except Exception:  # reported as absent, never fatal
+            graph_ms = None
     flags = np.zeros(n_cols, dtype=bool)
     flags[col] = True
     return {"workload": workload, "D": D, "N": n_local, "E": E, "n_cols": n_cols, "elem": elem, "header": header,
             "elapsed": elapsed, "steps": steps, "kernel_ms": kern_ms, "prep_cold_ms": prep[0], "prep_warm_ms": prep[1],
-            "n_gather_panels": n_gather_panels, "cols_referenced": int(flags.sum()), "x_rows": n_cols}
+            "n_gather_panels": n_gather_panels, "cols_referenced": int(flags.sum()), "x_rows": n_cols,
+            "hip_graph_ms_per_step": graph_ms}
 
 
 def roofline_of(case, traffic=None, traffic_source=None):
@@ -557,6 +581,9 @@ def sweep(fe, dev, args, rp_head, col_head):
                  "value": case["E"] * D / (case["elapsed"] / steps), "unit": "edge*dim/s",
                  "sparse_tasks": h.n_tasks, "dense_windows": h.n_dense, "nnz_dense": h.nnz_dense, "split_rows": h.n_split_rows,
                  "preprocess_ms": case["prep_warm_ms"], "graph_gen_s": round(gen_s, 1), "roofline": roof, "desc": desc}
+            if case.get("hip_graph_ms_per_step") is not None:
+                e["hip_graph_ms_per_step"] = case["hip_graph_ms_per_step"]
+                e["hip_graph_note"] = "the same step captured in a HIP graph and replayed: launch-bound workload, the Python call costs more than the kernel"
             if rec:
                 for k in ("l2_hit_rate", "mfma_util_percent", "mfma_flops_per_launch"):
                     if rec.get(k) is not None:

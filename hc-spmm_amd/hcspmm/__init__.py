@@ -55,12 +55,13 @@ def mi355x_rule(embedding_dim):
 # fingerprinted on the device once (hcspmm_graph_fingerprint_device) and refused unless it matches the header.
 # ---------------------------------------------------------------------------------------------
 class _Entry:
-    __slots__ = ("ref", "header", "graphs")
+    __slots__ = ("ref", "header", "graphs", "checked")
 
     def __init__(self, plan_t, header):
         self.ref = weakref.ref(plan_t)
         self.header = header
         self.graphs = collections.OrderedDict()  # (rowptr ptr, col ptr) -> (weakref, weakref)
+        self.checked = None                      # (N, E, numel) hcspmm_plan_check has passed for
 
 
 _REG = collections.OrderedDict()
@@ -158,6 +159,23 @@ def fused_in_launch(row_nzr, embedding_dim, hidden_dim):
 
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr() if t is not None and t.numel() > 0 else 0)
+
+
+class _on_device:
+    """`with torch.cuda.device(d)` only when d is not already current (the context manager costs a few microseconds,
+    which is the whole kernel time on a Cora-scale graph)."""
+    __slots__ = ("ctx",)
+
+    def __init__(self, device):
+        self.ctx = None if device.index is None or device.index == torch.cuda.current_device() else torch.cuda.device(device)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
 
 
 def _i32_host(t):
@@ -286,7 +304,9 @@ def _checked_header(row_nzr, row_pointers, column_index, N, E, x_rows):
     e = _entry(row_nzr, N, E) if (row_nzr is not None and row_nzr.is_cuda) else None
     if e is None:
         return None
-    check(lib().hcspmm_plan_check(ctypes.byref(e.header), N, E, row_nzr.numel()))
+    if e.checked != (N, E, row_nzr.numel()):
+        check(lib().hcspmm_plan_check(ctypes.byref(e.header), N, E, row_nzr.numel()))
+        e.checked = (N, E, row_nzr.numel())
     if x_rows < e.header.num_columns:
         raise RuntimeError("input has %d rows but the plan gathers from %d" % (x_rows, e.header.num_columns))
     _verify_graph(e, row_pointers, column_index)
@@ -306,7 +326,7 @@ def _spmm(X, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow
         if ws_bytes:
             ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=X.device)
     stream = ctypes.c_void_p(torch.cuda.current_stream(X.device).cuda_stream)
-    with torch.cuda.device(X.device):
+    with _on_device(X.device):
         check(L.hcspmm_forward_typed(_ptr(X), X.size(0), D, _ptr(Z), D, _DTYPES[X.dtype], _ptr(row_pointers), _ptr(column_index),
                                      _ptr(blockPartition), _ptr(edgeToColumn), _ptr(edgeToRow), _ptr(hybrid_type),
                                      _ptr(row_nzr) if h is not None else ctypes.c_void_p(0),
@@ -357,7 +377,7 @@ def forward_into(X, Z, row_pointers, column_index, blockPartition, edgeToColumn,
             else:
                 ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=X.device)
     stream = ctypes.c_void_p(torch.cuda.current_stream(X.device).cuda_stream)
-    with torch.cuda.device(X.device):
+    with _on_device(X.device):
         check(L.hcspmm_forward_typed(_ptr(X), X.size(0), X.stride(0), _ptr(Z), Z.stride(0), _DTYPES[X.dtype], _ptr(row_pointers),
                                      _ptr(column_index), _ptr(blockPartition), _ptr(edgeToColumn), _ptr(edgeToRow),
                                      _ptr(hybrid_type), _ptr(row_nzr) if h is not None else ctypes.c_void_p(0),
@@ -413,7 +433,7 @@ def _fused(X, row_pointers, column_index, blockPartition, edgeToColumn, edgeToRo
         if ws_bytes:
             ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=X.device)
     stream = ctypes.c_void_p(torch.cuda.current_stream(X.device).cuda_stream)
-    with torch.cuda.device(X.device):
+    with _on_device(X.device):
         check(L.hcspmm_forward_fused(_ptr(X), _ptr(output), _ptr(out2), _ptr(weights), weights.stride(0),
                                      weights.stride(1), H, _ptr(row_pointers), _ptr(column_index),
                                      _ptr(blockPartition), _ptr(edgeToColumn), _ptr(edgeToRow), _ptr(hybrid_type),

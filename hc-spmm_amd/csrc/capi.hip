@@ -298,17 +298,19 @@ extern "C" int hcspmm_forward(const float* X, float* Z, const int32_t* rowptr, c
                                 N, E, D, workspace, workspace_bytes, stream_v);
 }
 
-// Single-launch form of the fused operators: the dense-tile windows of a planned launch multiply their tile by the
+// In-launch form of the fused operators: the dense-tile windows of a planned launch multiply their tile by the
 // weights while it is in the MFMA accumulators (spmm_impl.h fused_dense_region); only the windows on the sparse-row
 // path -- listed in the plan (off_sparse_windows) -- go through the update kernel afterwards.  Taken when the plan
-// has dense windows and the shape is in range: fp32, D and H multiples of 16, H <= 64, W fits the LDS staging
-// area, 16-byte aligned rows.  HCSPMM_FUSED_SINGLE_LAUNCH=0 restores the two-launch form (A/B: profiles/r02/ab_fused.log).
+// asks for it (hcspmm_plan_params.fuse_in_launch; HCSPMM_FUSED_SINGLE_LAUNCH=1 / 0 forces it on / off for every
+// plan), has dense windows and the shape is in range: fp32, D a multiple of 16 from 32 up, H = 16 or 32, W fits the
+// LDS staging area, 16-byte aligned rows.  Not the default: on MI355X it is the slower form (profiles/r02/ab_fused.log).
 static bool fused_single_launch_ok(const hcspmm_plan_header* ph, const void* X, const void* out2, int D, int H) {
-  static const bool enabled = [] {
+  static const int forced = [] {
     const char* e = getenv("HCSPMM_FUSED_SINGLE_LAUNCH");
-    return !(e && e[0] == '0');
+    return !e ? -1 : (e[0] == '0' ? 0 : 1);
   }();
-  if (!enabled || !ph || ph->n_dense <= 0) return false;
+  if (!ph || ph->n_dense <= 0) return false;
+  if (forced == 0 || (forced < 0 && !(ph->flags & HCSPMM_PLAN_FUSE_IN_LAUNCH))) return false;
   if (D % 16 != 0 || D < 32 || H % 16 != 0 || H > 32 || H <= 0) return false;
   if (!aligned(X, 16) || !aligned(out2, 16)) return false;
   const int dv = D >= 64 ? 4 : 2;

@@ -38,14 +38,15 @@
 namespace {
 
 struct Resolved {
-  int32_t split_threshold, segment_len;
+  int32_t split_threshold, segment_len, fuse_in_launch;
 };
 
 Resolved resolve(const hcspmm_plan_params* p) {
-  Resolved r{512, 256};
+  Resolved r{512, 256, 0};
   if (p) {
     if (p->split_threshold > 0) r.split_threshold = p->split_threshold;
     if (p->segment_len > 0) r.segment_len = p->segment_len;
+    r.fuse_in_launch = p->fuse_in_launch != 0;
   }
   if (r.segment_len > r.split_threshold) r.segment_len = r.split_threshold;
   return r;
@@ -409,6 +410,7 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
   h.fingerprint_lo = (uint32_t)(fingerprint & 0xffffffffull);
   h.fingerprint_hi = (uint32_t)(fingerprint >> 32);
   h.dense_k_sum = (int32_t)std::min<int64_t>(L.dense_k_sum, INT32_MAX);
+  h.flags = rp.fuse_in_launch ? HCSPMM_PLAN_FUSE_IN_LAUNCH : 0;
   static_assert(sizeof(hcspmm_plan_header) == HCSPMM_PLAN_HEADER_WORDS * 4, "header size");
   std::memcpy(plan, &h, sizeof(h));
   return HCSPMM_OK;

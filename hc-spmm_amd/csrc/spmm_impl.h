@@ -163,11 +163,16 @@ template <int L> struct TinyT {
   static constexpr int per_group = HCSPMM_TINY_PER_WAVE / (64 / L);
   static constexpr int value = per_group < 2 ? 2 : (per_group > 4 ? 4 : per_group);
 };
+#ifndef HCSPMM_MIN_WAVES_H16
+#define HCSPMM_MIN_WAVES_H16 4  // fp16 / bf16 builds (8 elements per lane, widened in registers): 119 registers; at 96 they spill 150+ bytes
+#endif
 #ifndef HCSPMM_FUSED_MIN_WAVES
 #define HCSPMM_FUSED_MIN_WAVES 4
 #endif
 #ifndef HCSPMM_MIN_WAVES_PER_SIMD
-#define HCSPMM_MIN_WAVES_PER_SIMD 4  // <= 128 registers per lane (measured best with U = B = 8: profiles/r01/ab_u_b_mw_v2.log)
+#define HCSPMM_MIN_WAVES_PER_SIMD 5  // <= 96 registers per lane: five waves per SIMD.  Round 1 asked for four and got five by luck (94 registers);
+                                     // when round 2's refactoring nudged the kernel to 100 registers the low-degree workloads lost 10 %
+                                     // (profiles/r02/ab_occupancy.log), so the bound is now explicit
 #endif
 
 // One branch-free batch of UB row gathers: every lane issues all UB loads (finished tasks and lanes
@@ -925,6 +930,7 @@ static hipError_t launch_plan_LV(const PlanArgs& a, hipStream_t stream) {
   b.dense_vec = (a.D >= 16 * VEC) ? VEC : (a.D >= kMidCols ? VM : 1);
   b.n_panels = (a.D + 16 * b.dense_vec - 1) / (16 * b.dense_vec);
   constexpr bool kCanFuse = sizeof(typename E::T) == 4 && VEC == 4;
+  constexpr int kMinWaves = sizeof(typename E::T) == 4 ? HCSPMM_MIN_WAVES_PER_SIMD : HCSPMM_MIN_WAVES_H16;
   if (a.fused && !kCanFuse) return hipErrorInvalidValue;  // the caller checked (capi.hip fused_single_launch_ok)
   const long long dense_units = (long long)a.n_dense * (a.fused ? 1 : b.n_panels);  // fused: a wave owns a window
   long long dense_wgs = (dense_units + kWaves - 1) / kWaves;
@@ -947,11 +953,11 @@ static hipError_t launch_plan_LV(const PlanArgs& a, hipStream_t stream) {
         hipLaunchKernelGGL((hybrid_plan_kernel<E, L, VEC, HCSPMM_SPARSE_U, HCSPMM_FUSED_MIN_WAVES, true>),
                            dim3((unsigned)grid), dim3(kThreads), lds, stream, b);
       } else {
-        hipLaunchKernelGGL((hybrid_plan_kernel<E, L, VEC, HCSPMM_SPARSE_U, HCSPMM_MIN_WAVES_PER_SIMD>), dim3((unsigned)grid),
+        hipLaunchKernelGGL((hybrid_plan_kernel<E, L, VEC, HCSPMM_SPARSE_U, kMinWaves>), dim3((unsigned)grid),
                            dim3(kThreads), 0, stream, b);
       }
     } else {
-      hipLaunchKernelGGL((hybrid_plan_kernel<E, L, VEC, HCSPMM_SPARSE_U, HCSPMM_MIN_WAVES_PER_SIMD>), dim3((unsigned)grid),
+      hipLaunchKernelGGL((hybrid_plan_kernel<E, L, VEC, HCSPMM_SPARSE_U, kMinWaves>), dim3((unsigned)grid),
                          dim3(kThreads), 0, stream, b);
     }
   }

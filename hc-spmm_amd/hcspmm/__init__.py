@@ -29,7 +29,8 @@ __all__ = [
 ]
 
 _DEFAULT_RULE = int(os.environ.get("HCSPMM_RULE", RULE_INTENDED))
-_PLAN_PARAMS = PlanParams(int(os.environ.get("HCSPMM_SPLIT_THRESHOLD", 0)), int(os.environ.get("HCSPMM_SEGMENT_LEN", 0)))
+_PLAN_PARAMS = PlanParams(int(os.environ.get("HCSPMM_SPLIT_THRESHOLD", 0)), int(os.environ.get("HCSPMM_SEGMENT_LEN", 0)),
+                          int(os.environ.get("HCSPMM_FUSE_IN_LAUNCH", 0)))
 
 
 def set_default_rule(rule):
@@ -250,14 +251,16 @@ def preprocess(column_index, row_pointers, num_nodes, num_edges, num_row_windows
 
 
 def build_plan(row_pointers, column_index, blockPartition, edgeToColumn, hybrid_type, device=None,
-               split_threshold=0, segment_len=0, num_columns=None):
+               split_threshold=0, segment_len=0, num_columns=None, fuse_in_launch=False):
     """Launch plan for an arbitrary window classification (e.g. every window forced onto one sub-path,
-    or a classifier of the caller's own): -> plan tensor to pass as `row_nzr`."""
+    or a classifier of the caller's own): -> plan tensor to pass as `row_nzr`.  fuse_in_launch: the fused
+    operators update this plan's dense-tile windows inside the hybrid launch (include/hcspmm.h hcspmm_forward_fused)."""
     L = lib()
     rp_h, col_h = _i32_host(row_pointers), _i32_host(column_index)
     bp_h, e2c_h, ht_h = _i32_host(blockPartition), _i32_host(edgeToColumn), _i32_host(hybrid_type)
     N, E = rp_h.numel() - 1, col_h.numel()
-    params = PlanParams(int(split_threshold), int(segment_len)) if (split_threshold or segment_len) else _PLAN_PARAMS
+    params = PlanParams(int(split_threshold), int(segment_len), int(bool(fuse_in_launch))) \
+        if (split_threshold or segment_len or fuse_in_launch) else _PLAN_PARAMS
     words = ctypes.c_int64(0)
     check(L.hcspmm_plan_words(_ptr(rp_h), N, E, _ptr(bp_h), _ptr(ht_h), ctypes.byref(params), ctypes.byref(words)))
     plan = torch.empty(max(int(words.value), Header.WORDS), dtype=torch.int32)

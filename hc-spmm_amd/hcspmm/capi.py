@@ -3,7 +3,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "csrc", "libhcspmm.so"))
+# HCSPMM_LIB: another build of the same library (A/B runs of kernel variants on one box); default = the in-tree build
+LIB_PATH = os.environ.get("HCSPMM_LIB") or os.path.normpath(os.path.join(_HERE, "..", "csrc", "libhcspmm.so"))
 
 RULE_INTENDED = 0
 RULE_INTENDED_GUARD = 1
@@ -27,7 +28,7 @@ class Header(ctypes.Structure):
                                                                                   ("off_dense_compact2", ctypes.c_int32), ("num_columns", ctypes.c_int32),
                                                                                   ("n_sparse_windows", ctypes.c_int32), ("off_sparse_windows", ctypes.c_int32),
                                                                                   ("fingerprint_lo", ctypes.c_uint32), ("fingerprint_hi", ctypes.c_uint32),
-                                                                                  ("dense_k_sum", ctypes.c_int32), ("reserved", ctypes.c_int32 * 28)]
+                                                                                  ("dense_k_sum", ctypes.c_int32), ("flags", ctypes.c_int32), ("reserved", ctypes.c_int32 * 27)]
 
     @property
     def fingerprint(self):
@@ -36,7 +37,7 @@ class Header(ctypes.Structure):
 
 class PlanParams(ctypes.Structure):
     """hcspmm_plan_params."""
-    _fields_ = [("split_threshold", ctypes.c_int32), ("segment_len", ctypes.c_int32)]
+    _fields_ = [("split_threshold", ctypes.c_int32), ("segment_len", ctypes.c_int32), ("fuse_in_launch", ctypes.c_int32)]
 
 
 # every exported symbol of include/hcspmm.h: name -> (restype, argtypes)

@@ -144,13 +144,20 @@ typedef struct hcspmm_plan_header {
   uint32_t fingerprint_hi;  /* built from: a plan for another graph with the same N and E is told apart by it */
   int32_t dense_k_sum;      /* sum over dense windows of K = 8*blockPartition (padded condensed columns): the
                                dense-tile path executes exactly 2*16*K*D flop per window */
-  int32_t reserved[28];
+  int32_t flags;            /* HCSPMM_PLAN_FUSE_IN_LAUNCH: the fused operators update this plan's dense-tile windows inside the
+                               hybrid launch (hcspmm_plan_params.fuse_in_launch) */
+  int32_t reserved[27];
 } hcspmm_plan_header;
+
+#define HCSPMM_PLAN_FUSE_IN_LAUNCH 1
 
 /* Tunables for the plan; zero-initialise for defaults. */
 typedef struct hcspmm_plan_params {
   int32_t split_threshold; /* default 512 */
   int32_t segment_len;     /* default 256 */
+  int32_t fuse_in_launch;  /* != 0: hcspmm_forward_fused multiplies the dense-tile windows by the weights inside the
+                              hybrid launch (see there).  Default 0: measured on MI355X the two-launch form is 0-8 % faster
+                              (profiles/r02/ab_fused.log) */
 } hcspmm_plan_params;
 
 /* Number of int32 words a plan for this graph needs (so the caller can allocate the tensor). */
@@ -263,15 +270,20 @@ int32_t hcspmm_wide_threshold_typed(const hcspmm_plan_header* header_h, int embe
  * (bindings B.cpp:310-498) and their kernels K.cu:1639-2770.
  * `out_d` may be a caller-owned buffer (forward_final_fused writes the caller's `output`).
  *
- * With a plan that has dense-tile windows, fp32, D and H multiples of 16 and H <= 64, those windows are updated
+ * Two forms.  Default: the hybrid launch (out2 = A * X) followed by one streaming MFMA update launch over all rows.
+ * In-launch form, for a plan built with hcspmm_plan_params.fuse_in_launch (or HCSPMM_FUSED_SINGLE_LAUNCH=1 in the
+ * environment) that has dense-tile windows, fp32, D a multiple of 16 from 32 up, H = 16 or 32: those windows are updated
  * INSIDE the hybrid launch: the aggregation runs with exchanged MFMA operands, which leaves each lane holding one
  * row of the 16 x D tile in exactly the A-operand shape of the (tile x weights) MFMAs, so the tile goes from the
  * accumulators straight into the update (W staged in LDS) without touching LDS or HBM -- the reference keeps it in
  * shared memory (K.cu:1807-1837).  The windows on the sparse-row path, whose rows are spread over unrelated waves
  * by the length-sorted task schedule, are then multiplied by a second launch restricted to them (the plan lists
- * them: off_sparse_windows).  Otherwise: the hybrid launch + one update launch over all rows.
+ * them: off_sparse_windows).  The in-launch kernel needs 128 registers (four waves per SIMD against the plain
+ * kernel's five) and puts ~100 MFMAs per window on the critical path of latency-bound waves, which on this chip costs
+ * more than re-reading out2 from the Infinity Cache saves: it is the slower form here, kept for the record and for
+ * chips where the balance differs (A/B: profiles/r02/ab_fused.log).
  * hcspmm_fused_in_launch() tells which form a (plan, D, H) gets (1 = dense windows update in the hybrid launch);
- * HCSPMM_FUSED_SINGLE_LAUNCH=0 in the environment forces the two-launch form.
+ * HCSPMM_FUSED_SINGLE_LAUNCH=0 / 1 in the environment forces the two-launch / in-launch form for every plan.
  * ---------------------------------------------------------------------------------------- */
 int hcspmm_fused_in_launch(const hcspmm_plan_header* header_h, int embedding_dim, int hidden_dim);
 int hcspmm_forward_fused(const float* X_d, float* out_d, float* out2_d, const float* weights_d,

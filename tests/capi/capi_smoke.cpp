@@ -67,7 +67,7 @@ int main() {
   HC_OK(hcspmm_preprocess_host(rowptr.data(), col.data(), N, E, N, HCSPMM_RULE_INTENDED, 2, bp.data(), e2c.data(), e2r.data(),
                                ht.data()));
   int64_t words = 0;
-  hcspmm_plan_params pp = {256, 128};  // make the hub row split
+  hcspmm_plan_params pp = {256, 128, 0};  // make the hub row split
   HC_OK(hcspmm_plan_words(rowptr.data(), N, E, bp.data(), ht.data(), &pp, &words));
   std::vector<int32_t> plan((size_t)words);
   HC_OK(hcspmm_plan_build(rowptr.data(), col.data(), N, E, N, bp.data(), e2c.data(), ht.data(), &pp, plan.data(), words));

@@ -364,15 +364,21 @@ def _wide_window_graph(seed=11):
 @pytest.mark.parametrize("D,H", [(32, 32), (64, 64), (96, 22), (32, 7), (16, 40), (128, 32), (48, 16), (256, 32), (16, 16),
                                  (96, 16), (128, 64), (64, 32), (32, 16), (512, 32)])
 @pytest.mark.parametrize("gname,gen", _FUSED_GRAPHS, ids=[g[0] for g in _FUSED_GRAPHS])
-def test_fused_variants(oracle_mod, dev, fe, gname, gen, D, H):
-    """out2 = A*X, out = out2 * W for every fused name of the reference's module.  With dense-tile windows and D, H
-    multiples of 16 (H <= 64) those windows are updated inside the hybrid launch (transposed-tile MFMA chain); the
-    wide_windows graph is forced all-dense so that every record kind takes that path."""
+@pytest.mark.parametrize("form", ["two_launches", "in_launch"])
+def test_fused_variants(oracle_mod, dev, fe, gname, gen, D, H, form):
+    """out2 = A*X, out = out2 * W for every fused name of the reference's module, in both forms of the operator: the
+    default (hybrid launch + update launch) and, for plans built with fuse_in_launch, dense-tile windows updated inside
+    the hybrid launch (transposed-tile MFMA chain) where the shape allows; the wide_windows graph is forced all-dense so
+    that every record kind takes that path."""
     rp, col = gen()
     g = Graph(rp, col, dev, fe=fe, force_type=1 if gname == "wide_windows" else None)
+    assert not hcspmm.fused_in_launch(g.row_nzr, 32, 32)  # the default plan: two launches
+    if form == "in_launch":
+        g.row_nzr = fe.build_plan(g.rp_d, g.col_d, g.bp, g.e2c, g.ht, fuse_in_launch=True)
     in_launch = hcspmm.fused_in_launch(g.row_nzr, D, H)
-    # in the launch: fp32, D a multiple of 16 from 32 up, H = 16 or 32 (output tiles held in registers), W fits the LDS staging area
-    assert in_launch == (g.header().n_dense > 0 and D % 16 == 0 and D >= 32 and H in (16, 32) and D * (H + 4) * 4 <= 64 * 1024)
+    # in the launch: asked for, fp32, D a multiple of 16 from 32 up, H = 16 or 32 (output tiles held in registers), W fits the LDS staging area
+    assert in_launch == (form == "in_launch" and g.header().n_dense > 0 and D % 16 == 0 and D >= 32 and H in (16, 32)
+                         and D * (H + 4) * 4 <= 64 * 1024)
     if gname != "powerlaw":
         assert g.header().n_dense > 0
     rng = np.random.default_rng(7)

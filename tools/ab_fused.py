@@ -2,7 +2,7 @@
   two-launch form  : hybrid SpMM launch (writes out2 = A*X) + streaming MFMA update launch over ALL rows;
   in-launch form   : dense-tile windows multiply their tile by W inside the hybrid launch (tile kept in the MFMA
                      accumulators), update launch restricted to the sparse-row windows.
-Each form runs in its own process (the switch HCSPMM_FUSED_SINGLE_LAUNCH is read once per process).
+Each form runs in its own process (HCSPMM_FUSED_SINGLE_LAUNCH = 0 / 1 forces the form for every plan; read once).
 
   python tools/ab_fused.py            -> prints one table; the builder keeps it as profiles/r02/ab_fused.log
 """

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Randomised parity soak on the GPU: random graphs (sizes, degree laws, hubs, empty rows), embedding widths,
 feature types, classifier rules / forced sub-paths, plan tunables (tiny split thresholds so that segments,
-fix-ups and tiny segments appear everywhere) and the plan-free kernel -- every result checked against the CPU
-oracle with the criteria of tests/test_spmm_gpu.py.  Test infrastructure (it imports the oracle, so it lives under
+fix-ups and tiny segments appear everywhere), the plan-free kernel, BOTH front-ends (ctypes glue / HCSPMM extension)
+and the fused operators in both forms (two launches / dense windows updated in the launch) -- every result checked
+against the CPU oracle with the criteria of tests/test_spmm_gpu.py.  Test infrastructure (it imports the oracle, so it lives under
 tests/), but not collected by pytest -- it costs minutes of GPU time:
 
   python tests/fuzz_parity.py [--cases 300] [--seed 1]
@@ -19,6 +20,7 @@ import torch  # noqa: E402
 import hcspmm  # noqa: E402
 import oracle  # noqa: E402
 from hcspmm import graphs  # noqa: E402
+import frontends  # noqa: E402
 import test_spmm_gpu as T  # noqa: E402  (Graph, _check, _check_h16)
 
 
@@ -65,13 +67,19 @@ def main():
         mode = str(rng.choice(["rule0", "rule2", "rule3", "rule4", "all_dense", "all_sparse", "plan_free", "tiny_splits"]))
         dtype = [torch.float32, torch.float16, torch.bfloat16][int(rng.integers(0, 3))]
         rule = {"rule2": 2, "rule3": 3, "rule4": 4}.get(mode, 0)
-        g = T.Graph(rp, col, dev, rule=rule, plan=(mode != "plan_free"), force_type={"all_dense": 1, "all_sparse": 0}.get(mode))
+        fe = frontends.get(["ctypes", "extension"][int(rng.integers(0, 2))])
+        g = T.Graph(rp, col, dev, rule=rule, plan=(mode != "plan_free"), force_type={"all_dense": 1, "all_sparse": 0}.get(mode), fe=fe)
         if mode == "tiny_splits":  # rows longer than 5 entries are cut into segments of 1..5
-            g.row_nzr = hcspmm.build_plan(g.rp_d, g.col_d, g.bp, g.e2c, g.ht, split_threshold=int(rng.integers(2, 6)),
-                                          segment_len=int(rng.integers(1, 6)))
+            g.row_nzr = fe.build_plan(g.rp_d, g.col_d, g.bp, g.e2c, g.ht, split_threshold=int(rng.integers(2, 6)),
+                                      segment_len=int(rng.integers(1, 6)))
         X = rng.standard_normal((N, D)).astype(np.float32)
         strided = mode != "plan_free" and rng.random() < 0.3  # X and Z as column slices of wider matrices
-        tag = "%s/%s%s" % (mode, str(dtype).replace("torch.", ""), "/strided" if strided else "")
+        fused = dtype == torch.float32 and mode != "plan_free" and not strided and rng.random() < 0.35
+        in_launch = fused and rng.random() < 0.6
+        if in_launch:  # the same classification, plan flagged so that dense windows update inside the hybrid launch
+            g.row_nzr = fe.build_plan(g.rp_d, g.col_d, g.bp, g.e2c, g.ht, fuse_in_launch=True)
+        tag = "%s/%s%s%s/%s" % (mode, str(dtype).replace("torch.", ""), "/strided" if strided else "",
+                                ("/fused_in_launch" if in_launch else "/fused") if fused else "", fe.name)
 
         def run(Xd):
             if not strided:
@@ -80,11 +88,21 @@ def main():
             wide_x = torch.zeros(N, D + offx + int(rng.integers(0, 9)), dtype=Xd.dtype, device=dev)
             wide_z = torch.full((N, D + offz + int(rng.integers(0, 9))), 7.0, dtype=Xd.dtype, device=dev)
             wide_x[:, offx:offx + D] = Xd
-            hcspmm.forward_into(wide_x[:, offx:offx + D], wide_z[:, offz:offz + D], *g.args())
+            fe.forward_into(wide_x[:, offx:offx + D], wide_z[:, offz:offz + D], *g.args())
             assert bool((wide_z[:, :offz] == 7).all()) and bool((wide_z[:, offz + D:] == 7).all()), "wrote outside its slice"
             return wide_z[:, offz:offz + D].contiguous()
         try:
-            if dtype == torch.float32:
+            if fused:
+                H = int(rng.choice([16, 32, 32, 7, 64, 48]))
+                Wm = rng.standard_normal((D, H)).astype(np.float32)
+                Xd, Wd = torch.from_numpy(X).to(dev), torch.from_numpy(Wm).to(dev)
+                out, out2 = fe.forward_fixed32_fused(Xd, *g.args(), Wd)
+                T._check(oracle, g, X, out2)
+                assert torch.equal(out2, g.forward(Xd)), "fused out2 differs from the plain forward"
+                want, _ = oracle.spmm_fused_f32(rp, col, X, Wm)
+                scale = oracle.spmm_f64(rp, col, X, absolute=True) @ np.abs(Wm).astype(np.float64)
+                assert np.all(np.abs(out.cpu().numpy().astype(np.float64) - want) <= 1e-5 * scale + 1e-30), "fused out off"
+            elif dtype == torch.float32:
                 T._check(oracle, g, X, run(torch.from_numpy(X).to(dev)))
             else:
                 X16 = torch.from_numpy(X).to(dtype).to(dev)

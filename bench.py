@@ -179,7 +179,7 @@ def live_pmc(args, cache_dir, passes):
         try:
             p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, start_new_session=True)
             try:
-                log, _ = p.communicate(timeout=300)
+                log, _ = p.communicate(timeout=150)
             except subprocess.TimeoutExpired:
                 os.killpg(p.pid, 9)
                 p.wait()
@@ -455,6 +455,7 @@ def main():
             np.save(os.path.join(cache_dir, "rp.npy"), rp)
             np.save(os.path.join(cache_dir, "col.npy"), col)
     pmc = None
+    import torch  # (importing does not initialise the GPU; doing it first pages the library in for the child processes too)
     if world == 1 and not args.pmc_child and not args.no_pmc:
         cache_dir = tempfile.mkdtemp(prefix="hcspmm_bench_")
         own_cache = True
@@ -463,7 +464,6 @@ def main():
         passes = [p for p in os.environ.get("HCSPMM_BENCH_PMC", "fetch,write,l2").split(",") if p in PMC_PASSES]
         pmc = live_pmc(args, cache_dir, passes)
 
-    import torch
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the hot path has no CPU fallback", file=sys.stderr)
         sys.exit(2)

@@ -537,6 +537,18 @@ def main():
                        "kernel_src_sha": kernel_src_sha()},
             "roofline": roof,
         }
+        if world > 1:
+            # the one exchange of the path: every rank receives the other ranks' X row blocks each step.  On the 8-GPU full
+            # mesh (7 xGMI links x 153.6 GB/s bidirectional per GPU) an all-gather is bound by ONE link per peer.
+            recv = float(world - 1) * n_local * D * case["elem"]
+            out["communication"] = {"collective": "all_gather_into_tensor (RCCL) of X, %d column panel(s), panel-major buffers, no copies"
+                                                  % case["n_gather_panels"],
+                                    "bytes_received_per_rank_per_step": recv,
+                                    "one_link_per_peer_bound_ms": n_local * D * case["elem"] / 76.8e9 * 1e3,
+                                    "local_product_ms": case["kernel_ms"],
+                                    "exposed_ms": ms_per_step - case["kernel_ms"],
+                                    "note": "communication-bound by construction (DESIGN.md section 6): the gathered bytes grow with the "
+                                            "world size while the local product does not; only the last panel's product is exposed"}
         torch.cuda.empty_cache()
         if world == 1 and not args.no_sweep:
             out["sweep"] = sweep(fe, dev, args, rp, col)

@@ -64,38 +64,67 @@ struct Layout {
           off_sparse_windows = 0, total = 0;
 };
 
+// Runs fn(t) for t in [0, T) on T threads (T == 1: inline).
+template <typename F> void parallel_for(int T, F fn) {
+  if (T <= 1) { fn(0); return; }
+  std::vector<std::thread> th;
+  th.reserve((size_t)T);
+  for (int t = 0; t < T; ++t) th.emplace_back(fn, t);
+  for (auto& x : th) x.join();
+}
+
+// host threads for the plan passes: they are memory-bound and start their threads several times over, so beyond 16
+// threads they get slower (3.6 / 3.7 / 5.6 / 10 / 20 ms at 8 / 16 / 32 / 64 / 128 threads on the Reddit-scale graph)
+int plan_threads(int64_t W) { return W < 4096 ? 1 : std::min(hcspmm::host_threads(), 16); }
+
 int compute_layout(const int32_t* rowptr, int64_t N, const int32_t* bp, const int32_t* ht, const Resolved& rp,
                    Layout* out) {
-  Layout L;
   const int64_t W = (N + HCSPMM_BLK_H - 1) / HCSPMM_BLK_H;
-  for (int64_t w = 0; w < W; ++w) {
-    const int64_t r0 = w * HCSPMM_BLK_H, r1 = std::min<int64_t>(r0 + HCSPMM_BLK_H, N);
-    const int64_t nnz = (int64_t)rowptr[r1] - rowptr[r0];
-    if (ht[w] != 0 && nnz > 0) {
-      if (bp[w] <= 0) return HCSPMM_EINVAL;
-      L.n_dense++;
-      const int64_t K = (int64_t)bp[w] * HCSPMM_BLK_W;
-      if (K <= HCSPMM_COMPACT_K) L.n_compact++;
-      else if (K <= HCSPMM_COMPACT2_K) L.n_compact2++;
-      else L.dense_pack_words += K + (K / 4) * 2;  // U[K] + one 64-bit mask per 4 columns
-      L.nnz_dense += nnz;
-      L.dense_k_sum += K;
-      L.max_dense_k = std::max<int32_t>(L.max_dense_k, (int32_t)K);
-    } else {
-      L.n_sparse_windows++;
-      for (int64_t r = r0; r < r1; ++r) {
-        const int64_t d = (int64_t)rowptr[r + 1] - rowptr[r];
-        if (d > rp.split_threshold) {
-          const int64_t segs = (d + rp.segment_len - 1) / rp.segment_len;
-          L.n_tasks += segs;
-          L.n_partials += segs;
-          L.n_split_rows++;
-        } else {
-          L.n_tasks++;
+  const int T = plan_threads(W);
+  std::vector<Layout> part((size_t)T);
+  std::vector<int> bad((size_t)T, 0);
+  parallel_for(T, [&](int t) {  // counts are sums over windows: any split gives the same totals
+    Layout L;
+    for (int64_t w = W * t / T; w < W * (t + 1) / T; ++w) {
+      const int64_t r0 = w * HCSPMM_BLK_H, r1 = std::min<int64_t>(r0 + HCSPMM_BLK_H, N);
+      const int64_t nnz = (int64_t)rowptr[r1] - rowptr[r0];
+      if (ht[w] != 0 && nnz > 0) {
+        if (bp[w] <= 0) { bad[(size_t)t] = 1; return; }
+        L.n_dense++;
+        const int64_t K = (int64_t)bp[w] * HCSPMM_BLK_W;
+        if (K <= HCSPMM_COMPACT_K) L.n_compact++;
+        else if (K <= HCSPMM_COMPACT2_K) L.n_compact2++;
+        else L.dense_pack_words += K + (K / 4) * 2;  // U[K] + one 64-bit mask per 4 columns
+        L.nnz_dense += nnz;
+        L.dense_k_sum += K;
+        L.max_dense_k = std::max<int32_t>(L.max_dense_k, (int32_t)K);
+      } else {
+        L.n_sparse_windows++;
+        for (int64_t r = r0; r < r1; ++r) {
+          const int64_t d = (int64_t)rowptr[r + 1] - rowptr[r];
+          if (d > rp.split_threshold) {
+            const int64_t segs = (d + rp.segment_len - 1) / rp.segment_len;
+            L.n_tasks += segs;
+            L.n_partials += segs;
+            L.n_split_rows++;
+          } else {
+            L.n_tasks++;
+          }
         }
+        L.nnz_sparse += nnz;
       }
-      L.nnz_sparse += nnz;
     }
+    part[(size_t)t] = L;
+  });
+  Layout L;
+  for (int t = 0; t < T; ++t) {
+    if (bad[(size_t)t]) return HCSPMM_EINVAL;
+    const Layout& p = part[(size_t)t];
+    L.n_tasks += p.n_tasks; L.n_dense += p.n_dense; L.n_compact += p.n_compact; L.n_compact2 += p.n_compact2;
+    L.n_split_rows += p.n_split_rows; L.n_partials += p.n_partials; L.dense_pack_words += p.dense_pack_words;
+    L.nnz_sparse += p.nnz_sparse; L.nnz_dense += p.nnz_dense; L.dense_k_sum += p.dense_k_sum;
+    L.n_sparse_windows += p.n_sparse_windows;
+    L.max_dense_k = std::max(L.max_dense_k, p.max_dense_k);
   }
   L.off_tasks = HCSPMM_PLAN_HEADER_WORDS;
   L.off_dense_index = align4(L.off_tasks + 4 * L.n_tasks);
@@ -130,20 +159,10 @@ static inline int length_class(int32_t len) {
   return c;
 }
 
-// Runs fn(t) for t in [0, T) on T threads (T == 1: inline).
-template <typename F> static void parallel_for(int T, F fn) {
-  if (T <= 1) { fn(0); return; }
-  std::vector<std::thread> th;
-  th.reserve((size_t)T);
-  for (int t = 0; t < T; ++t) th.emplace_back(fn, t);
-  for (auto& x : th) x.join();
-}
-
 // fingerprint of (rowptr, col) + range check of col against [0, M): one parallel pass over both arrays
 static int fingerprint_and_check(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, int64_t M, uint64_t* out) {
   if (rowptr[0] != 0 || rowptr[N] != E) return HCSPMM_EINVAL;
-  int T = hcspmm::host_threads();
-  if (N + E < (1 << 18)) T = 1;
+  const int T = (N + E < (1 << 18)) ? 1 : std::min(hcspmm::host_threads(), 16);
   std::vector<uint64_t> part((size_t)T, 0);
   std::vector<int> bad((size_t)T, 0);
   parallel_for(T, [&](int t) {
@@ -196,13 +215,15 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
 
   // Threads work on contiguous window ranges; every output position follows from per-thread counts in
   // range order, so the blob is identical for any thread count.
-  int T = hcspmm::host_threads();
-  if (W < 4096) T = 1;
+  const int T = plan_threads(W);
   std::vector<int64_t> cut((size_t)T + 1);
   for (int t = 0; t <= T; ++t) cut[(size_t)t] = W * t / T;
-  {  // zero the blob (padding, masks) in parallel: it is tens of MB for a multi-million-row graph
+  {  // zero what the passes below do not overwrite word for word: everything behind the task list (masks are OR-ed
+     // in, records and section gaps are padded).  The task list itself -- 16 bytes per row, 78 of the 80 MB of a
+     // 4.9 M-row plan -- is written completely, so it is not cleared first.
+    const int64_t z0 = L.off_dense_index, zn = L.total - z0;
     std::vector<int64_t> zc((size_t)T + 1);
-    for (int t = 0; t <= T; ++t) zc[(size_t)t] = L.total * t / T;
+    for (int t = 0; t <= T; ++t) zc[(size_t)t] = z0 + zn * t / T;
     parallel_for(T, [&](int t) {
       std::memset(plan + zc[(size_t)t], 0, sizeof(int32_t) * (size_t)(zc[(size_t)t + 1] - zc[(size_t)t]));
     });

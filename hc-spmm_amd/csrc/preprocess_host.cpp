@@ -60,7 +60,7 @@ inline int classify(int32_t size, uint32_t nnz, int32_t num, int rule) {
 void process_windows(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t M, int64_t w_begin, int64_t w_end,
                      int rule, int32_t* blockPartition, int32_t* edgeToColumn, int32_t* edgeToRow, int32_t* hybrid_type,
                      int* bad) {
-  std::vector<int32_t> uniq;
+  std::vector<int32_t> uniq, buf_a, buf_b;
   for (int64_t w = w_begin; w < w_end; ++w) {
     const int64_t r0 = w * HCSPMM_BLK_H, r1 = std::min<int64_t>(r0 + HCSPMM_BLK_H, N);
     const int64_t lo = rowptr[r0], hi = rowptr[r1];
@@ -77,8 +77,43 @@ void process_windows(const int32_t* rowptr, const int32_t* col, int64_t N, int64
       hybrid_type[w] = 0;
       continue;
     }
-    uniq.assign(col + lo, col + hi);
-    std::sort(uniq.begin(), uniq.end());
+    // The window's ascending unique column list (what the reference gets from thrust::sort + in-place dedupe,
+    // K.cu:386-399, :213-223).  Rows arrive ascending (dataset.py's scipy tocsr), so the list is a 16-way merge:
+    // a tree of pairwise merges over two scratch buffers, four passes over the window's entries instead of a sort
+    // (which was most of the host pass: 3x on the Reddit-scale graph).  A row that is not ascending falls back to
+    // the sort, so any input gives the same list.
+    bool rows_ascending = true;
+    for (int64_t r = r0; r < r1 && rows_ascending; ++r)
+      for (int64_t e = (int64_t)rowptr[r] + 1; e < rowptr[r + 1]; ++e)
+        if (col[e - 1] > col[e]) { rows_ascending = false; break; }
+    if (!rows_ascending) {
+      uniq.assign(col + lo, col + hi);
+      std::sort(uniq.begin(), uniq.end());
+    } else {
+      const size_t m = (size_t)(hi - lo);
+      buf_a.assign(col + lo, col + hi);
+      buf_b.resize(m);
+      int64_t cuts[HCSPMM_BLK_H + 1];  // run boundaries, relative to lo
+      int runs = 0;
+      for (int64_t r = r0; r <= r1; ++r) cuts[runs++] = (int64_t)rowptr[r] - lo;
+      --runs;  // number of rows = number of sorted runs
+      int32_t *src = buf_a.data(), *dst = buf_b.data();
+      while (runs > 1) {
+        int out_runs = 0;
+        for (int i = 0; i + 1 < runs; i += 2) {
+          std::merge(src + cuts[i], src + cuts[i + 1], src + cuts[i + 1], src + cuts[i + 2], dst + cuts[i]);
+          cuts[out_runs++] = cuts[i];
+        }
+        if (runs & 1) {
+          std::copy(src + cuts[runs - 1], src + cuts[runs], dst + cuts[runs - 1]);
+          cuts[out_runs++] = cuts[runs - 1];
+        }
+        cuts[out_runs] = (int64_t)m;
+        runs = out_runs;
+        std::swap(src, dst);
+      }
+      uniq.assign(src, src + m);
+    }
     uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
     const int32_t size = (int32_t)uniq.size() - 1;                      // K.cu:256-257
     const int32_t num = (size + HCSPMM_BLK_W) / HCSPMM_BLK_W;           // K.cu:258

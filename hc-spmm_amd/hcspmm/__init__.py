@@ -215,10 +215,12 @@ def preprocess(column_index, row_pointers, num_nodes, num_edges, num_row_windows
     W = (N + 15) // 16
     if int(num_row_windows) != W:
         raise RuntimeError("preprocess: num_row_windows (%d) != ceil(N/16) (%d)" % (num_row_windows, W))
-    bp = torch.empty(W, dtype=torch.int32)
-    ht = torch.empty(W, dtype=torch.int32)
-    e2c = torch.empty(E, dtype=torch.int32)
     on_gpu = dev.type == "cuda"
+    # host outputs in pinned memory when they are headed for the GPU (torch's caching host allocator recycles the blocks
+    # from call to call): the uploads run at PCIe rate and asynchronously instead of through a pageable staging copy
+    bp = torch.empty(W, dtype=torch.int32, pin_memory=on_gpu)
+    ht = torch.empty(W, dtype=torch.int32, pin_memory=on_gpu)
+    e2c = torch.empty(E, dtype=torch.int32, pin_memory=on_gpu)
     # edgeToRow is the plain CSR row expansion: made on the device when the graph lives there -- fill_edgeToRow
     # (K.cu:314-337) as one small HIP kernel of the library, enqueued now so that it runs under the host passes below
     e2r = None
@@ -240,11 +242,11 @@ def preprocess(column_index, row_pointers, num_nodes, num_edges, num_row_windows
         e2r = e2r_h
     words = ctypes.c_int64(0)
     check(L.hcspmm_plan_words(_ptr(rp_h), N, E, _ptr(bp), _ptr(ht), ctypes.byref(_PLAN_PARAMS), ctypes.byref(words)))
-    plan = torch.empty(max(int(words.value), Header.WORDS), dtype=torch.int32)
+    plan = torch.empty(max(int(words.value), Header.WORDS), dtype=torch.int32, pin_memory=on_gpu)
     check(L.hcspmm_plan_build(_ptr(rp_h), _ptr(col_h), N, E, M, _ptr(bp), _ptr(e2c), _ptr(ht),
                               ctypes.byref(_PLAN_PARAMS), _ptr(plan), plan.numel()))
     h = Header.from_buffer_copy(plan[:Header.WORDS].numpy().tobytes())
-    outs = [t.to(dev) for t in (bp, e2c, e2r, ht, plan)]  # .to() is a no-op for the device-made e2r
+    outs = [t.to(dev, non_blocking=True) for t in (bp, e2c, e2r, ht, plan)]  # .to() is a no-op for the device-made e2r
     _register(outs[4], h, row_pointers, column_index)
     col_nzr = torch.zeros(1, dtype=torch.int32, device=dev)
     return [outs[0], outs[1], outs[2], outs[3], outs[4], col_nzr]

@@ -264,7 +264,10 @@ std::vector<torch::Tensor> preprocess(torch::Tensor edgeList_tensor, torch::Tens
   TORCH_CHECK(block_num == W, "preprocess: num_row_windows (", block_num, ") != ceil(N/16) (", W, ")");
   const int64_t M = num_columns > 0 ? num_columns : N;
   auto opts = torch::TensorOptions().dtype(torch::kInt);
-  auto bp = torch::empty({W}, opts), ht = torch::empty({W}, opts), e2c = torch::empty({E}, opts);
+  // host outputs in pinned memory when they are headed for the GPU (the caching host allocator recycles the blocks):
+  // the uploads run at PCIe rate, asynchronously, instead of through a pageable staging copy
+  auto hopts = opts.pinned_memory(dev.is_cuda());
+  auto bp = torch::empty({W}, hopts), ht = torch::empty({W}, hopts), e2c = torch::empty({E}, hopts);
   // edgeToRow is the plain CSR row expansion (reference fill_edgeToRow, K.cu:314-326): made on the
   // device when the graph lives there, so 4*E bytes skip the host round trip
   torch::Tensor e2r;
@@ -283,16 +286,16 @@ std::vector<torch::Tensor> preprocess(torch::Tensor edgeList_tensor, torch::Tens
            "preprocess");
   int64_t words = 0;
   check_rc(hcspmm_plan_words(rp.data_ptr<int>(), N, E, iptr(bp), iptr(ht), &g_params, &words), "preprocess(plan size)");
-  auto plan = torch::empty({std::max<int64_t>(words, HCSPMM_PLAN_HEADER_WORDS)}, opts);
+  auto plan = torch::empty({std::max<int64_t>(words, HCSPMM_PLAN_HEADER_WORDS)}, hopts);
   check_rc(hcspmm_plan_build(rp.data_ptr<int>(), iptr(col), N, E, M, iptr(bp), iptr(e2c), iptr(ht), &g_params,
                              plan.data_ptr<int>(), plan.numel()),
            "preprocess(plan build)");
   hcspmm_plan_header h;
   std::memcpy(&h, plan.data_ptr<int>(), sizeof(h));
-  auto plan_d = plan.to(dev);
+  auto plan_d = plan.to(dev, /*non_blocking=*/true);
   if (plan_d.is_cuda()) remember(plan_d, h, &nodePointer_tensor, &edgeList_tensor);
   auto col_nzr = torch::zeros({1}, opts).to(dev);  // stays the reference's placeholder (K.cu:405)
-  return {bp.to(dev), e2c.to(dev), e2r.to(dev), ht.to(dev), plan_d, col_nzr};
+  return {bp.to(dev, true), e2c.to(dev, true), e2r.to(dev), ht.to(dev, true), plan_d, col_nzr};
 }
 
 #define HCSPMM_GRAPH_PARAMS                                                                                   \

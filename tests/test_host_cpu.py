@@ -97,6 +97,23 @@ def test_preprocess_bit_exact_vs_oracle(oracle_mod, name, gen, rule):
     assert got[5].tolist() == [0]  # col_nzr stays the reference's placeholder (hybrid_all_kernel.cu:405)
 
 
+def test_preprocess_handles_rows_that_are_not_ascending(oracle_mod):
+    """dataset.py hands over ascending rows, and the window pass exploits that (a 16-way merge instead of a sort); the
+    reference's sort + binary search copes with any order, and so must we: same integers as the oracle on rows whose
+    entries were shuffled (every window then takes the sorting fallback for its column list)."""
+    rp, col = graphs.planted_dense_graph(900, seed=31)
+    rng = np.random.default_rng(1)
+    col = col.copy()
+    for r in rng.choice(len(rp) - 1, 300, replace=False):
+        seg = col[rp[r]:rp[r + 1]]
+        rng.shuffle(seg)
+    for rule in (0, 2):
+        want = oracle_mod.preprocess(rp, col, rule)
+        got = _pre(rp, col, rule)
+        for w, g in zip(want, got[:4]):
+            assert np.array_equal(w, g.numpy())
+
+
 def test_preprocess_multithreaded_equals_single(capi):
     rp, col = graphs.powerlaw_graph(60000, 400000, seed=5)
     N, E = len(rp) - 1, len(col)

@@ -167,6 +167,10 @@ def live_pmc(args, cache_dir, passes):
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof):
         return {"error": "rocprofv3 not found"}
+    # already inside a profiler (this very command run under rocprofv3, e.g. by tools/profile_round.sh or a harness)?  Then no
+    # nested profiler runs: the recorded figures are used instead
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return {"error": "already running under a profiler: live counter passes skipped"}
     out = {"passes": {}, "counters": {}}
     child = ["python3", os.path.join(ROOT, "bench.py"), "--pmc-child", "--graph-cache", cache_dir, "--workload", args.workload,
              "--dim", str(args.dim), "--steps", "4", "--warmup", "2", "--rule", str(args.rule), "--dtype", args.dtype,

@@ -1,0 +1,37 @@
+import ctypes, sys
+import os; R=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0]=[R, os.path.join(R,'hc-spmm_amd')]
+import numpy as np
+from hcspmm import graphs
+L=ctypes.CDLL(sys.argv[1])
+vp=ctypes.c_void_p; i64=ctypes.c_int64
+def P(a): return vp(a.ctypes.data) if a is not None and a.size else vp(0)
+rng=np.random.default_rng(0)
+n_ok=0
+for trial in range(40):
+    kind=trial%5
+    N=int(rng.choice([1,15,16,17,50,64,333,1000,5000,70000]))
+    if kind==0: rp,col=graphs.powerlaw_graph(max(N,8),max(N,8)*int(rng.integers(1,20)),seed=trial,max_degree_frac=float(rng.choice([0.02,0.9])))
+    elif kind==1: rp,col=graphs.uniform_graph(max(N,4),max(N,4)*int(rng.integers(0,8))+1,seed=trial)
+    elif kind==2: rp,col=graphs.planted_dense_graph_fast(max(N,32),seed=trial,dense_fraction=0.5,k_cols=int(rng.choice([4,20,41,64,130])),fill=0.5,sparse_degree=3)
+    elif kind==3: rp,col=graphs.molecule_graph(max(N,50),seed=trial)
+    else:
+        n=max(N,1); rp,col=np.zeros(n+1,np.int32),np.zeros(0,np.int32)
+    N=len(rp)-1; E=len(col); W=(N+15)//16
+    for rule in (0,2,4):
+        bp=np.zeros(W,np.int32); ht=np.zeros(W,np.int32); e2c=np.zeros(E,np.int32); e2r=np.zeros(E,np.int32)
+        rc=L.hcspmm_preprocess_host(P(rp),P(col),i64(N),i64(E),i64(N),rule,int(rng.choice([0,1,3])),P(bp),P(e2c),P(e2r),P(ht)); assert rc==0,rc
+        for force in (None,1):
+            h2=ht if force is None else np.ones_like(ht)
+            words=i64(0); rc=L.hcspmm_plan_words(P(rp),i64(N),i64(E),P(bp),P(h2),None,ctypes.byref(words)); assert rc==0
+            plan=np.zeros(max(words.value,64),np.int32)
+            rc=L.hcspmm_plan_build(P(rp),P(col),i64(N),i64(E),i64(N),P(bp),P(e2c),P(h2),None,P(plan),i64(len(plan))); assert rc==0,rc
+    perm=np.zeros(N,np.int32); gs=np.zeros(max(N,1),np.int32); ng=i64(0)
+    if E < 400000:
+        for variant in (0,1,2,3):
+            rc=L.hcspmm_loi_reorder_variant(P(rp),P(col),i64(N),i64(E),variant,P(perm),P(gs),ctypes.byref(ng))
+            assert rc in (0,-1), rc
+        rp2=np.zeros(N+1,np.int32); col2=np.zeros(E,np.int32)
+        L.hcspmm_loi_reorder_variant(P(rp),P(col),i64(N),i64(E),0,P(perm),P(gs),ctypes.byref(ng))
+        rc=L.hcspmm_apply_permutation(P(rp),P(col),i64(N),i64(E),P(perm),P(rp2),P(col2)); assert rc==0
+    n_ok+=1
+print('asan/ubsan host run ok:',n_ok,'graphs')

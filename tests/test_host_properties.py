@@ -1,0 +1,124 @@
+"""Property tests (hypothesis) of the host side of the path on small ragged graphs -- empty rows, N < 16, N % 16 != 0,
+hub rows, duplicate-free random rows: preprocess integers == oracle for every rule; the plan blob accounts for every
+stored entry exactly once (sparse tasks + dense windows), lists exactly the non-dense windows, carries the graph's
+fingerprint, and passes its own consistency check; LOI reorders are permutations that apply as graph isomorphisms."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+import hcspmm
+from hcspmm.capi import Header
+
+from test_host_cpu import _decode_plan, _expand_tiny
+
+
+@st.composite
+def csr_graphs(draw):
+    N = draw(st.integers(1, 90))
+    seed = draw(st.integers(0, 2 ** 31 - 1))
+    shape = draw(st.sampled_from(["sparse", "dense_windows", "hubs", "mostly_empty"]))
+    rng = np.random.default_rng(seed)
+    if shape == "sparse":
+        deg = rng.integers(0, min(N, 6) + 1, N)
+    elif shape == "mostly_empty":
+        deg = (rng.random(N) < 0.2) * rng.integers(1, min(N, 4) + 1, N)
+    elif shape == "hubs":
+        deg = rng.integers(0, 3, N)
+        deg[rng.integers(0, N, 2)] = N
+    else:
+        deg = rng.integers(0, min(N, 10) + 1, N)
+    deg = np.minimum(deg, N)
+    cols = []
+    for w0 in range(0, N, 16):
+        pool = rng.choice(N, min(N, int(rng.integers(1, 25))), replace=False) if shape == "dense_windows" else None
+        for r in range(w0, min(w0 + 16, N)):
+            d = int(deg[r])
+            if pool is not None:
+                d = min(d, len(pool))
+                deg[r] = d
+                cols.append(np.sort(rng.choice(pool, d, replace=False)))
+            else:
+                cols.append(np.sort(rng.choice(N, d, replace=False)))
+    rp = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    col = (np.concatenate(cols) if cols else np.zeros(0)).astype(np.int32)
+    return rp, col
+
+
+SETTINGS = dict(max_examples=60, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large])
+
+
+@settings(**SETTINGS)
+@given(csr_graphs(), st.sampled_from([0, 1, 2, 3, 4]))
+def test_preprocess_equals_oracle(oracle_mod, g, rule):
+    rp, col = g
+    N = len(rp) - 1
+    got = hcspmm.preprocess(torch.from_numpy(col), torch.from_numpy(rp), N, len(col), (N + 15) // 16, rule=rule)
+    want = oracle_mod.preprocess(rp, col, rule)
+    for w, t in zip(want, got[:4]):
+        assert np.array_equal(w, t.numpy())
+
+
+@settings(**SETTINGS)
+@given(csr_graphs(), st.sampled_from([0, 2, "all_dense"]), st.integers(2, 6), st.integers(1, 6))
+def test_plan_covers_every_entry_exactly_once(capi, g, mode, split, seg):
+    rp, col = g
+    N, E = len(rp) - 1, len(col)
+    W = (N + 15) // 16
+    bp, e2c, e2r, ht, _, _ = hcspmm.preprocess(torch.from_numpy(col), torch.from_numpy(rp), N, E, W, rule=0 if mode == "all_dense" else mode)
+    if mode == "all_dense":
+        ht = torch.ones_like(ht)
+    plan = hcspmm.build_plan(torch.from_numpy(rp), torch.from_numpy(col), bp, e2c, ht, split_threshold=split, segment_len=min(seg, split)).numpy()
+    h, tasks, dindex, fix = _decode_plan(plan)
+    L = capi.lib()
+    assert L.hcspmm_plan_check(ctypes.byref(h), N, E, len(plan)) == 0
+    fp = ctypes.c_uint64(0)
+    assert L.hcspmm_graph_fingerprint_host(rp.ctypes.data, col.ctypes.data, N, E, ctypes.byref(fp)) == 0 and fp.value == h.fingerprint
+    cover = np.zeros(E, np.int32)
+    for row, e0, ln, slot in _expand_tiny(h, tasks, fix, rp, col):
+        assert rp[row] <= e0 and e0 + ln <= rp[row + 1]
+        cover[e0:e0 + ln] += 1
+    win_nnz = np.array([rp[min(16 * w + 16, N)] - rp[16 * w] for w in range(W)])
+    dense_w = [w for w in range(W) if ht[w] != 0 and win_nnz[w] > 0]
+    assert sorted(dindex[:, 0].tolist()) == dense_w and h.n_dense == len(dense_w)
+    for w in dense_w:
+        cover[rp[16 * w]:rp[min(16 * w + 16, N)]] += 1
+    assert np.all(cover == 1)
+    sparse_list = plan[h.off_sparse_windows:h.off_sparse_windows + h.n_sparse_windows].tolist()
+    assert sparse_list == [w for w in range(W) if w not in set(dense_w)]
+    assert h.nnz_dense == int(win_nnz[dense_w].sum()) and h.nnz_sparse == E - h.nnz_dense
+    assert h.dense_k_sum == int(sum(8 * int(bp[w]) for w in dense_w))
+    # split rows: every row longer than the threshold on the sparse path has a fix-up entry covering its segments
+    deg = np.diff(rp)
+    long_rows = [r for r in range(N) if deg[r] > split and (r // 16) not in set(dense_w)]
+    assert sorted(fix[:, 0].tolist()) == long_rows
+    for row, s0, ns, _ in fix:
+        assert ns == -(-deg[row] // min(seg, split))
+
+
+@settings(**SETTINGS)
+@given(csr_graphs(), st.sampled_from(["new_direct", "new"]))
+def test_loi_reorder_is_a_permutation_and_relabelling_is_an_isomorphism(g, variant):
+    rp, col = g
+    N = len(rp) - 1
+    perm, sizes = hcspmm.loi_reorder(torch.from_numpy(rp), torch.from_numpy(col), variant=variant)
+    p = perm.numpy()
+    assert sorted(p.tolist()) == list(range(N))
+    # every row with entries is placed in a group of 1..16 rows (the `new` variant, which walks the column vertex's own
+    # out-list, may also pull rows WITHOUT entries into groups of an asymmetric graph); the rest follows ascending
+    n_grouped = int(sizes.sum())
+    assert int((np.diff(rp) > 0).sum()) <= n_grouped <= N and (sizes.numpy() <= 16).all() and (sizes.numpy() >= 1).all()
+    if variant == "new_direct":
+        assert n_grouped == int((np.diff(rp) > 0).sum())
+    tail = p[n_grouped:]
+    assert np.all(np.diff(tail) > 0) and np.all(np.diff(rp)[tail] == 0)
+    rp2, col2 = hcspmm.apply_permutation(torch.from_numpy(rp), torch.from_numpy(col), perm)
+    rp2, col2 = rp2.numpy(), col2.numpy()
+    inv = np.empty(N, np.int64)
+    inv[p] = np.arange(N)
+    for new_r in range(N):
+        old = p[new_r]
+        assert sorted(inv[col[rp[old]:rp[old + 1]]].tolist()) == col2[rp2[new_r]:rp2[new_r + 1]].tolist()

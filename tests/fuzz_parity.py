@@ -111,6 +111,8 @@ def main():
             print("FAILED case %d: N=%d E=%d D=%d %s" % (case, N, len(col), D, tag))
             raise
         stats[tag] = stats.get(tag, 0) + 1
+        if (case + 1) % 500 == 0:
+            print("... %d cases ok" % (case + 1), flush=True)  # a long silent run is taken for a hang by gpurun
     torch.cuda.synchronize()
     print("fuzz ok: %d cases (seed %d)" % (args.cases, args.seed))
     for k in sorted(stats):

@@ -166,3 +166,36 @@ def test_extension_weight_grad_and_layer_backward_use_it(HCSPMM, oracle_mod):
     (Ad @ (Xd @ Wd)).backward(G.double())
     assert torch.allclose(W.grad.double(), Wd.grad, rtol=1e-4, atol=1e-4 * float(Wd.grad.abs().max()))
     assert torch.allclose(X.grad.double(), Xd.grad, rtol=1e-4, atol=1e-4 * float(Xd.grad.abs().max()))
+
+
+@pytest.mark.gpu
+def test_extension_plan_params_select_the_in_launch_fused_form(HCSPMM, oracle_mod):
+    """HCSPMM.set_plan_params(split, segment, fuse_in_launch): plans made by the following preprocess calls ask the fused
+    operators to update dense-tile windows inside the hybrid launch; the default (and a reset) is the two-launch form.
+    Same results either way."""
+    dev = torch.device("cuda:0")
+    rp, col = graphs.planted_dense_graph(1000, seed=8)
+    N = len(rp) - 1
+    rp_d, col_d = torch.from_numpy(rp).to(dev), torch.from_numpy(col).to(dev)
+    rng = np.random.default_rng(1)
+    X = rng.standard_normal((N, 64)).astype(np.float32)
+    W = rng.standard_normal((64, 32)).astype(np.float32)
+    Xd, Wd = torch.from_numpy(X).to(dev), torch.from_numpy(W).to(dev)
+    want_out, _ = oracle_mod.spmm_fused_f32(rp, col, X, W)
+    scale = oracle_mod.spmm_f64(rp, col, X, absolute=True) @ np.abs(W).astype(np.float64)
+    outs = HCSPMM.preprocess(col_d, rp_d, N, len(col), (N + 15) // 16)
+    assert not HCSPMM.fused_in_launch(outs[4], 64, 32) and HCSPMM.plan_info(outs[4])["flags"] == 0
+    ref_out, ref_out2 = HCSPMM.forward_fixed32_fused(Xd, rp_d, col_d, *outs, Wd)
+    HCSPMM.set_plan_params(0, 0, True)
+    try:
+        outs2 = HCSPMM.preprocess(col_d, rp_d, N, len(col), (N + 15) // 16)
+    finally:
+        HCSPMM.set_plan_params(0, 0)
+    assert HCSPMM.plan_info(outs2[4])["flags"] == 1 and HCSPMM.plan_info(outs2[4])["n_dense"] > 0
+    assert HCSPMM.fused_in_launch(outs2[4], 64, 32) and not HCSPMM.fused_in_launch(outs2[4], 64, 64)
+    out, out2 = HCSPMM.forward_fixed32_fused(Xd, rp_d, col_d, *outs2, Wd)
+    assert torch.equal(out2, ref_out2)
+    for o in (out, ref_out):
+        assert np.all(np.abs(o.cpu().numpy().astype(np.float64) - want_out) <= 1e-5 * scale + 1e-30)
+    outs3 = HCSPMM.preprocess(col_d, rp_d, N, len(col), (N + 15) // 16)
+    assert HCSPMM.plan_info(outs3[4])["flags"] == 0

@@ -72,7 +72,7 @@ static int panel_choice(const hcspmm_plan_header* h, int D, int dtype) {
   if (env > 0) return env >= D ? D : ((env + 15) / 16) * 16;
   const int line_cols = 128 / elem_bytes(dtype);  // 32 fp32 or 64 16-bit columns: one cache line per gathered row
   if (D < 2 * line_cols || h->n_tasks <= 0) return D;
-  const double mean_len = (double)h->nnz_sparse / (double)h->n_tasks;
+  const double mean_len = (double)h->nnz_sparse / ((double)h->n_tasks + (double)h->n_slice_tasks);
   return mean_len >= 8.0 ? line_cols : D;
 }
 
@@ -217,6 +217,12 @@ int forward_impl(const void* X, int64_t x_rows, int64_t ldx, void* Z, int64_t ld
     a.n_tasks = ph->n_tasks;
     a.n_tiny = ph->n_tiny;
     a.tiny_wgs = 0;
+    a.off_slice_table = ph->off_slice_table;
+    a.off_slice_tasks = ph->off_slice_tasks;
+    a.n_slices = ph->n_slices;
+    a.slice_xcd_tasks = ph->slice_xcd_tasks;
+    a.slice_wgs = 0;
+    a.free_wgs_pp = 0;
     a.off_dense_index = ph->off_dense_index;
     a.off_dense_pack = ph->off_dense_pack;
     a.n_dense = ph->n_dense;

@@ -21,10 +21,21 @@
 // indices -1 -- so that the kernel needs one memory round trip, not two, before it can gather.
 //   sparse windows : ids of the windows that are NOT dense (ascending) -- the 16-row tiles that the update pass
 //             of the fused operators still has to multiply by the weights (dense windows do it in the launch).
+//   slices  : XCD-affine column slices (hcspmm.h n_slices).  The launch is bound by the gathered X rows that miss the
+//             per-XCD L2, and workgroups b and b + 8 share an XCD (MI355X_MICROARCH.md, workgroup dispatch).  Rows
+//             longer than slice_threshold are therefore cut where their ascending column ids cross S - 1 boundaries
+//             (chosen so that every slice holds about the same number of those entries) and every segment_len
+//             entries; the pieces of slice s go to their own task list, which the kernel serves with workgroups
+//             b = s (mod 8) only.  The L2 of that XCD then sees 1/8 of the columns from those tasks -- on the
+//             Reddit-scale headline a 3.7 MB share of each 30 MB panel of X -- instead of all of them
+//             (tools/l2_hit_simulation.py: 56 % -> 82 % hits at threshold 64).  A column slice of a column-sorted row
+//             is a contiguous CSR range, so the pieces are ordinary (row, first, length, slot) tasks whose partial
+//             sums the fix-up pass adds in slice order = CSR order.
 // Blob layout (int32 words): header[64] | tasks[n_tasks][4] | dense_index[n_dense][4] |
 // dense_pack[...] | compact2[n_dense_compact2][128] | compact[n_dense_compact][64] | fixups[n_split_rows][4] |
-// sparse_windows[n_sparse_windows].
-// All section offsets are multiples of 4 words, the compact sections' of 64.
+// sparse_windows[n_sparse_windows] | slice_table[n_slices + 1] | slice_tasks[n_slice_tasks][4].
+// All section offsets are multiples of 4 words, the compact sections' of 64.  With slices the sections are sized
+// by upper bounds that do not depend on the column ids (hcspmm_plan_words has none): the header holds the real counts.
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
@@ -37,19 +48,56 @@
 
 namespace {
 
+constexpr int kSliceAuto = 0, kSliceOn = 1, kSliceOff = -1;
+constexpr int32_t kSliceAutoThreshold = 64;       // rows longer than this are sliced (tools/l2_hit_simulation.py, profiles/r03/ab_slices.log)
+constexpr int64_t kSliceAutoMinColumns = 65536;  // a 128-byte line per X row: below this a panel of X is within two L2s anyway
+constexpr int kSlicePad = 64;                    // slice lists are padded to whole waves of any lane-group count (4 waves x 16)
+
 struct Resolved {
   int32_t split_threshold, segment_len, fuse_in_launch;
+  int32_t slice_mode, slice_threshold, n_slices;
 };
 
+int env_int(const char* name, int dflt) {
+  const char* e = std::getenv(name);
+  return e && *e ? std::atoi(e) : dflt;
+}
+
 Resolved resolve(const hcspmm_plan_params* p) {
-  Resolved r{512, 256, 0};
+  Resolved r{512, 256, 0, kSliceAuto, kSliceAutoThreshold, 8};
   if (p) {
     if (p->split_threshold > 0) r.split_threshold = p->split_threshold;
     if (p->segment_len > 0) r.segment_len = p->segment_len;
     r.fuse_in_launch = p->fuse_in_launch != 0;
   }
   if (r.segment_len > r.split_threshold) r.segment_len = r.split_threshold;
+  int thr = p ? p->slice_threshold : 0, ns = p ? p->n_slices : 0;
+  if (thr == 0) thr = env_int("HCSPMM_SLICE_THRESHOLD", 0);  // A/B runs; explicit parameters win
+  if (ns == 0) ns = env_int("HCSPMM_SLICES", 0);
+  if (thr > 0) { r.slice_mode = kSliceOn; r.slice_threshold = thr; }
+  else if (thr < 0) r.slice_mode = kSliceOff;
+  if (ns > 0) r.n_slices = std::min(64, (ns + 7) / 8 * 8);
   return r;
+}
+
+// pieces a sliced row of d entries can fall into, whatever its column ids: every boundary and every segment_len
+// entries start at most one new piece
+inline int64_t pieces_bound(int64_t d, const Resolved& rp) {
+  return std::min<int64_t>(d, rp.n_slices - 1 + (d + rp.segment_len - 1) / rp.segment_len);
+}
+
+// The pieces of one sliced row: entries [e0, e0 + d) cut where the (ascending) column ids cross bounds[0 .. S-2]
+// (bounds[s] = first column id of slice s + 1) and every seg entries.  fn(slice, first entry, length), in CSR order.
+// Unsorted columns still give a partition of the row (placement loses its meaning, the sum does not).
+template <typename F>
+inline void for_each_piece(const int32_t* col, int32_t e0, int64_t d, const int32_t* bounds, int S, int32_t seg, F fn) {
+  const int32_t* first = col + e0;
+  int64_t lo = 0;
+  for (int s = 0; s < S && lo < d; ++s) {
+    const int64_t hi = (s == S - 1) ? d : std::lower_bound(first + lo, first + d, bounds[s]) - first;
+    for (int64_t b = lo; b < hi; b += seg) fn(s, (int32_t)(e0 + b), (int32_t)std::min<int64_t>(seg, hi - b));
+    lo = hi;
+  }
 }
 
 inline int64_t align4(int64_t x) { return (x + 3) & ~int64_t(3); }
@@ -60,8 +108,9 @@ struct Layout {
   int64_t nnz_sparse = 0, nnz_dense = 0, dense_k_sum = 0;
   int32_t max_dense_k = 0;
   int64_t n_sparse_windows = 0;
+  int64_t n_slice_tasks = 0, n_sliced_rows = 0, nnz_sliced = 0;  // with slices: n_slice_tasks, n_split_rows, n_partials are upper bounds
   int64_t off_tasks = 0, off_dense_index = 0, off_dense_pack = 0, off_compact2 = 0, off_compact = 0, off_fixups = 0,
-          off_sparse_windows = 0, total = 0;
+          off_sparse_windows = 0, off_slice_table = 0, off_slice_tasks = 0, total = 0;
 };
 
 // Runs fn(t) for t in [0, T) on T threads (T == 1: inline).
@@ -78,7 +127,7 @@ template <typename F> void parallel_for(int T, F fn) {
 int plan_threads(int64_t W) { return W < 4096 ? 1 : std::min(hcspmm::host_threads(), 16); }
 
 int compute_layout(const int32_t* rowptr, int64_t N, const int32_t* bp, const int32_t* ht, const Resolved& rp,
-                   Layout* out) {
+                   bool slicing, Layout* out) {
   const int64_t W = (N + HCSPMM_BLK_H - 1) / HCSPMM_BLK_H;
   const int T = plan_threads(W);
   std::vector<Layout> part((size_t)T);
@@ -102,7 +151,14 @@ int compute_layout(const int32_t* rowptr, int64_t N, const int32_t* bp, const in
         L.n_sparse_windows++;
         for (int64_t r = r0; r < r1; ++r) {
           const int64_t d = (int64_t)rowptr[r + 1] - rowptr[r];
-          if (d > rp.split_threshold) {
+          if (slicing && d > rp.slice_threshold) {
+            const int64_t pcs = pieces_bound(d, rp);
+            L.n_slice_tasks += pcs;
+            L.n_partials += pcs;
+            L.n_split_rows++;
+            L.n_sliced_rows++;
+            L.nnz_sliced += d;
+          } else if (d > rp.split_threshold) {
             const int64_t segs = (d + rp.segment_len - 1) / rp.segment_len;
             L.n_tasks += segs;
             L.n_partials += segs;
@@ -124,8 +180,10 @@ int compute_layout(const int32_t* rowptr, int64_t N, const int32_t* bp, const in
     L.n_split_rows += p.n_split_rows; L.n_partials += p.n_partials; L.dense_pack_words += p.dense_pack_words;
     L.nnz_sparse += p.nnz_sparse; L.nnz_dense += p.nnz_dense; L.dense_k_sum += p.dense_k_sum;
     L.n_sparse_windows += p.n_sparse_windows;
+    L.n_slice_tasks += p.n_slice_tasks; L.n_sliced_rows += p.n_sliced_rows; L.nnz_sliced += p.nnz_sliced;
     L.max_dense_k = std::max(L.max_dense_k, p.max_dense_k);
   }
+  if (slicing) L.n_slice_tasks += (int64_t)kSlicePad * rp.n_slices;  // every slice list is padded to a multiple of kSlicePad
   L.off_tasks = HCSPMM_PLAN_HEADER_WORDS;
   L.off_dense_index = align4(L.off_tasks + 4 * L.n_tasks);
   L.off_dense_pack = align4(L.off_dense_index + 4 * L.n_dense);
@@ -133,7 +191,9 @@ int compute_layout(const int32_t* rowptr, int64_t N, const int32_t* bp, const in
   L.off_compact = L.off_compact2 + HCSPMM_COMPACT2_WORDS * L.n_compact2;
   L.off_fixups = align4(L.off_compact + HCSPMM_COMPACT_WORDS * L.n_compact);
   L.off_sparse_windows = align4(L.off_fixups + 4 * L.n_split_rows);
-  L.total = align4(L.off_sparse_windows + L.n_sparse_windows);
+  L.off_slice_table = align4(L.off_sparse_windows + L.n_sparse_windows);
+  L.off_slice_tasks = slicing ? align4(L.off_slice_table + rp.n_slices + 1) : L.off_slice_table;
+  L.total = align4(L.off_slice_tasks + 4 * (slicing ? L.n_slice_tasks : 0));
   if (L.total > INT32_MAX) return HCSPMM_ERANGE;
   *out = L;
   return HCSPMM_OK;
@@ -145,10 +205,23 @@ extern "C" int hcspmm_plan_words(const int32_t* rowptr, int64_t N, int64_t E, co
                                  const hcspmm_plan_params* params, int64_t* words_out) {
   if (!rowptr || !words_out || N < 0 || E < 0) return HCSPMM_EINVAL;
   if (N > 0 && (!bp || !ht)) return HCSPMM_EINVAL;
-  Layout L;
-  const int rc = compute_layout(rowptr, N, bp, ht, resolve(params), &L);
-  if (rc != HCSPMM_OK) return rc;
-  *words_out = L.total;
+  // whether rows get sliced is decided where the column ids are known (hcspmm_plan_build): unless the parameters
+  // settle it, size the tensor for either outcome
+  const Resolved rp = resolve(params);
+  Layout L, Ls;
+  int rc = HCSPMM_OK;
+  int64_t total = 0;
+  if (rp.slice_mode != kSliceOn) {
+    rc = compute_layout(rowptr, N, bp, ht, rp, false, &L);
+    if (rc != HCSPMM_OK) return rc;
+    total = L.total;
+  }
+  if (rp.slice_mode != kSliceOff) {
+    rc = compute_layout(rowptr, N, bp, ht, rp, true, &Ls);
+    if (rc != HCSPMM_OK) return rc;
+    total = std::max(total, Ls.total);
+  }
+  *words_out = total;
   return HCSPMM_OK;
 }
 
@@ -208,10 +281,22 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
   }
   const Resolved rp = resolve(params);
   Layout L;
-  int rc = compute_layout(rowptr, N, bp, ht, rp, &L);
-  if (rc != HCSPMM_OK) return rc;
+  int rc = HCSPMM_OK;
+  // XCD-affine slices: asked for, or (automatic) worth it -- X spans many L2s and the long rows hold a real share
+  bool slicing = rp.slice_mode == kSliceOn;
+  if (rp.slice_mode != kSliceOff) {
+    rc = compute_layout(rowptr, N, bp, ht, rp, true, &L);
+    if (rc != HCSPMM_OK) return rc;
+    if (rp.slice_mode == kSliceAuto) slicing = M >= kSliceAutoMinColumns && L.nnz_sliced * 20 >= L.nnz_sparse && L.nnz_sliced > 0;
+    if (L.n_sliced_rows == 0) slicing = false;
+  }
+  if (!slicing) {
+    rc = compute_layout(rowptr, N, bp, ht, rp, false, &L);
+    if (rc != HCSPMM_OK) return rc;
+  }
   if (words < L.total) return HCSPMM_EINVAL;
   const int64_t W = (N + HCSPMM_BLK_H - 1) / HCSPMM_BLK_H;
+  const int S = slicing ? rp.n_slices : 0;
 
   // Threads work on contiguous window ranges; every output position follows from per-thread counts in
   // range order, so the blob is identical for any thread count.
@@ -229,6 +314,38 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
     });
   }
 
+  // ---- slice boundaries: bounds[s] = first column id of slice s + 1, chosen on a histogram of the sliced rows'
+  // entries (at most 65536 buckets) so that every slice holds about the same number of them -- equal work per XCD
+  std::vector<int32_t> bounds((size_t)std::max(S - 1, 0), 0);
+  if (slicing) {
+    int shift = 0;
+    while (((M - 1) >> shift) >= 65536) ++shift;
+    const int64_t nb = ((M - 1) >> shift) + 1;
+    std::vector<std::vector<int64_t>> hist((size_t)T, std::vector<int64_t>((size_t)nb, 0));
+    parallel_for(T, [&](int t) {
+      int64_t* h = hist[(size_t)t].data();
+      for (int64_t w = cut[(size_t)t]; w < cut[(size_t)t + 1]; ++w) {
+        const int64_t r0 = w * HCSPMM_BLK_H, r1 = std::min<int64_t>(r0 + HCSPMM_BLK_H, N);
+        if (ht[w] != 0 && rowptr[r1] > rowptr[r0]) continue;
+        for (int64_t r = r0; r < r1; ++r) {
+          if ((int64_t)rowptr[r + 1] - rowptr[r] <= rp.slice_threshold) continue;
+          for (int64_t e = rowptr[r]; e < rowptr[r + 1]; ++e) h[col[e] >> shift]++;
+        }
+      }
+    });
+    int64_t total = 0;
+    for (int64_t b = 0; b < nb; ++b) {
+      for (int t = 1; t < T; ++t) hist[0][(size_t)b] += hist[(size_t)t][(size_t)b];
+      total += hist[0][(size_t)b];
+    }
+    int64_t run = 0, b = 0;
+    for (int sidx = 0; sidx < S - 1; ++sidx) {
+      const int64_t want = (total * (sidx + 1) + S - 1) / S;
+      while (b < nb && run + hist[0][(size_t)b] <= want) run += hist[0][(size_t)b++];
+      bounds[(size_t)sidx] = (int32_t)std::min<int64_t>(M, b << shift);
+    }
+  }
+
   // ---- sparse tasks.  Order: by descending power-of-two length class (0, 1, 2, 3-4, 5-8, 9-16, ...), rows
   // ascending inside a class.  Classes keep the lane groups of a wave within 2x of each other and put the
   // heavy work first; row order inside a class keeps the Z stores, the column-index reads and the
@@ -239,10 +356,11 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
   const int n_cls = length_class(rp.split_threshold) + 1;
   struct Counts {
     std::vector<int64_t> cls;
+    std::vector<int64_t> slice_cls;  // [slice][class]
     int64_t n_fix = 0, n_slots = 0, n_dense = 0, n_sparse_w = 0;
   };
   std::vector<Counts> cnt((size_t)T);
-  auto walk = [&](int t, auto&& on_task, auto&& on_fix, auto&& on_dense, auto&& on_sparse_window) {
+  auto walk = [&](int t, auto&& on_task, auto&& on_fix, auto&& on_dense, auto&& on_sparse_window, auto&& on_piece) {
     for (int64_t w = cut[(size_t)t]; w < cut[(size_t)t + 1]; ++w) {
       const int64_t r0 = w * HCSPMM_BLK_H, r1 = std::min<int64_t>(r0 + HCSPMM_BLK_H, N);
       const int64_t nnz = (int64_t)rowptr[r1] - rowptr[r0];
@@ -254,7 +372,16 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
       for (int64_t r = r0; r < r1; ++r) {
         const int32_t e0 = rowptr[r];
         const int64_t d = (int64_t)rowptr[r + 1] - e0;
-        if (d > rp.split_threshold) {
+        if (slicing && d > rp.slice_threshold) {
+          // a row that falls into one piece needs no partial sum; otherwise its pieces take consecutive slots in CSR order
+          int64_t pcs = 0, k = 0;
+          for_each_piece(col, e0, d, bounds.data(), S, rp.segment_len, [&](int, int32_t, int32_t) { ++pcs; });
+          const int64_t slot0 = pcs > 1 ? on_fix(r, pcs) : -1;
+          for_each_piece(col, e0, d, bounds.data(), S, rp.segment_len, [&](int sl, int32_t first, int32_t len) {
+            on_piece(sl, (int32_t)r, first, len, (int32_t)(pcs > 1 ? slot0 + k : -1));
+            ++k;
+          });
+        } else if (d > rp.split_threshold) {
           const int64_t segs = (d + rp.segment_len - 1) / rp.segment_len;
           const int64_t slot0 = on_fix(r, segs);
           for (int64_t sgm = 0; sgm < segs; ++sgm) {
@@ -270,9 +397,11 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
   parallel_for(T, [&](int t) {
     Counts& c = cnt[(size_t)t];
     c.cls.assign((size_t)n_cls, 0);
+    c.slice_cls.assign((size_t)S * (size_t)n_cls, 0);
     walk(t, [&](int32_t, int32_t, int32_t len, int32_t) { c.cls[(size_t)length_class(len)]++; },
          [&](int64_t, int64_t segs) { c.n_fix++; c.n_slots += segs; return (int64_t)0; },
-         [&](int64_t) { c.n_dense++; }, [&](int64_t) { c.n_sparse_w++; });
+         [&](int64_t) { c.n_dense++; }, [&](int64_t) { c.n_sparse_w++; },
+         [&](int sl, int32_t, int32_t, int32_t len, int32_t) { c.slice_cls[(size_t)sl * (size_t)n_cls + (size_t)length_class(len)]++; });
   });
   // class starts (bucket 0 = longest class), then per-thread offsets inside each class, in range order
   std::vector<int64_t> start((size_t)n_cls + 1, 0);
@@ -305,16 +434,48 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
       sparse_w_at[(size_t)t + 1] = sparse_w_at[(size_t)t] + cnt[(size_t)t].n_sparse_w;
     }
   }
-  if (fix_at[(size_t)T] != L.n_split_rows || slot_at[(size_t)T] != L.n_partials || dense_at[(size_t)T] != L.n_dense ||
-      start.back() != L.n_tasks || sparse_w_at[(size_t)T] != L.n_sparse_windows)
-    return HCSPMM_EINVAL;  // (cannot happen: compute_layout counted the same things)
+  // (cannot happen: compute_layout counted the same things -- with slices, upper bounds of the first two)
+  if (slicing ? (fix_at[(size_t)T] > L.n_split_rows || slot_at[(size_t)T] > L.n_partials)
+              : (fix_at[(size_t)T] != L.n_split_rows || slot_at[(size_t)T] != L.n_partials))
+    return HCSPMM_EINVAL;
+  if (dense_at[(size_t)T] != L.n_dense || start.back() != L.n_tasks || sparse_w_at[(size_t)T] != L.n_sparse_windows)
+    return HCSPMM_EINVAL;
+  // slice lists: slice s owns descriptors [table[s], table[s+1]) (padded to whole waves), longest class first, and inside a
+  // class the threads' shares in range order (= rows ascending)
+  std::vector<int64_t> table((size_t)S + 1, 0);
+  std::vector<std::vector<int64_t>> spos((size_t)T, std::vector<int64_t>((size_t)S * (size_t)n_cls, 0));
+  int64_t slice_xcd_tasks = 0;
+  if (slicing) {
+    int64_t xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int sl = 0; sl < S; ++sl) {
+      int64_t run = table[(size_t)sl];
+      for (int c = n_cls - 1; c >= 0; --c)
+        for (int t = 0; t < T; ++t) {
+          spos[(size_t)t][(size_t)sl * (size_t)n_cls + (size_t)c] = run;
+          run += cnt[(size_t)t].slice_cls[(size_t)sl * (size_t)n_cls + (size_t)c];
+        }
+      const int64_t padded = (run - table[(size_t)sl] + kSlicePad - 1) / kSlicePad * kSlicePad;
+      int32_t* pad = plan + L.off_slice_tasks;
+      for (int64_t q = run; q < table[(size_t)sl] + padded; ++q) {
+        if (q >= L.n_slice_tasks) return HCSPMM_EINVAL;
+        pad[4 * q + 0] = -1; pad[4 * q + 1] = 0; pad[4 * q + 2] = 0; pad[4 * q + 3] = -1;
+      }
+      table[(size_t)sl + 1] = table[(size_t)sl] + padded;
+      xcd[sl & 7] += padded;
+    }
+    if (table[(size_t)S] > L.n_slice_tasks) return HCSPMM_EINVAL;
+    for (int x = 0; x < 8; ++x) slice_xcd_tasks = std::max(slice_xcd_tasks, xcd[x]);
+    for (int sl = 0; sl <= S; ++sl) plan[L.off_slice_table + sl] = (int32_t)table[(size_t)sl];
+  }
   struct DenseRef { int32_t w, K; };
   std::vector<DenseRef> dense((size_t)L.n_dense);
   int32_t* out = plan + L.off_tasks;
   int32_t* fix = plan + L.off_fixups;
   int32_t* sparse_w = plan + L.off_sparse_windows;
+  int32_t* sout = plan + L.off_slice_tasks;
   parallel_for(T, [&](int t) {
     std::vector<int64_t>& p = pos[(size_t)t];
+    std::vector<int64_t>& sp = spos[(size_t)t];
     int64_t n_fix = fix_at[(size_t)t], slot = slot_at[(size_t)t], nd = dense_at[(size_t)t], nsw = sparse_w_at[(size_t)t];
     walk(t,
          [&](int32_t row, int32_t e0, int32_t len, int32_t slot_id) {
@@ -341,7 +502,14 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
            return s0;
          },
          [&](int64_t w) { dense[(size_t)nd++] = DenseRef{(int32_t)w, bp[w] * HCSPMM_BLK_W}; },
-         [&](int64_t w) { sparse_w[nsw++] = (int32_t)w; });
+         [&](int64_t w) { sparse_w[nsw++] = (int32_t)w; },
+         [&](int sl, int32_t row, int32_t first, int32_t len, int32_t slot_id) {
+           const int64_t q = sp[(size_t)sl * (size_t)n_cls + (size_t)length_class(len)]++;
+           sout[4 * q + 0] = row;
+           sout[4 * q + 1] = first;
+           sout[4 * q + 2] = len;
+           sout[4 * q + 3] = slot_id;
+         });
   });
 
   // ---- dense windows: widest first (stable, so window order inside a width); pack U and the MFMA lane masks
@@ -409,8 +577,8 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
   h.segment_len = rp.segment_len;
   h.n_tasks = (int32_t)L.n_tasks;
   h.n_dense = (int32_t)L.n_dense;
-  h.n_split_rows = (int32_t)L.n_split_rows;
-  h.n_partials = (int32_t)L.n_partials;
+  h.n_split_rows = (int32_t)fix_at[(size_t)T];
+  h.n_partials = (int32_t)slot_at[(size_t)T];
   h.off_tasks = (int32_t)L.off_tasks;
   h.off_dense_index = (int32_t)L.off_dense_index;
   h.off_dense_pack = (int32_t)L.off_dense_pack;
@@ -432,6 +600,14 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
   h.fingerprint_hi = (uint32_t)(fingerprint >> 32);
   h.dense_k_sum = (int32_t)std::min<int64_t>(L.dense_k_sum, INT32_MAX);
   h.flags = rp.fuse_in_launch ? HCSPMM_PLAN_FUSE_IN_LAUNCH : 0;
+  h.n_slices = S;
+  h.slice_threshold = slicing ? rp.slice_threshold : 0;
+  h.off_slice_table = (int32_t)L.off_slice_table;
+  h.off_slice_tasks = (int32_t)L.off_slice_tasks;
+  h.n_slice_tasks = slicing ? (int32_t)table[(size_t)S] : 0;
+  h.slice_xcd_tasks = (int32_t)slice_xcd_tasks;
+  h.nnz_sliced = slicing ? (int32_t)L.nnz_sliced : 0;
+  h.n_sliced_rows = slicing ? (int32_t)L.n_sliced_rows : 0;
   static_assert(sizeof(hcspmm_plan_header) == HCSPMM_PLAN_HEADER_WORDS * 4, "header size");
   std::memcpy(plan, &h, sizeof(h));
   return HCSPMM_OK;
@@ -466,6 +642,17 @@ extern "C" int hcspmm_plan_check(const hcspmm_plan_header* h, int64_t N, int64_t
     return HCSPMM_EPLAN;
   if (h->off_sparse_windows < h->off_fixups + 4 * (int64_t)h->n_split_rows || (h->off_sparse_windows & 3)) return HCSPMM_EPLAN;
   if (h->total_words < h->off_sparse_windows + (int64_t)h->n_sparse_windows) return HCSPMM_EPLAN;
+  if (h->n_slices < 0 || h->n_slices > 64 || (h->n_slices & 7) || h->n_slice_tasks < 0 || h->slice_xcd_tasks < 0) return HCSPMM_EPLAN;
+  if (h->n_slices > 0) {
+    if (h->slice_threshold <= 0 || (h->n_slice_tasks % 64) || (h->slice_xcd_tasks % 64) || h->slice_xcd_tasks > h->n_slice_tasks)
+      return HCSPMM_EPLAN;
+    if (h->off_slice_table < h->off_sparse_windows + (int64_t)h->n_sparse_windows || (h->off_slice_table & 3)) return HCSPMM_EPLAN;
+    if (h->off_slice_tasks < h->off_slice_table + (int64_t)h->n_slices + 1 || (h->off_slice_tasks & 3)) return HCSPMM_EPLAN;
+    if (h->total_words < h->off_slice_tasks + 4 * (int64_t)h->n_slice_tasks) return HCSPMM_EPLAN;
+    if (h->nnz_sliced < 0 || h->nnz_sliced > h->nnz_sparse) return HCSPMM_EPLAN;
+  } else if (h->n_slice_tasks != 0 || h->slice_xcd_tasks != 0) {
+    return HCSPMM_EPLAN;
+  }
   if (words_available > 0 && h->total_words > words_available) return HCSPMM_EPLAN;
   if ((int64_t)h->nnz_sparse + h->nnz_dense != E) return HCSPMM_EPLAN;
   return HCSPMM_OK;

@@ -663,7 +663,8 @@ __device__ __forceinline__ void fused_dense_region(const PlanArgs& a, int lane, 
 // UNROLL row loads in flight per lane, MINW waves per SIMD the register budget must allow.  With the
 // branch-free batches <8, 4> is best for throughput- and latency-bound launches alike
 // (profiles/r01/ab_u_b_mw_v2.log; before them <4, 8> won: profiles/r01/ab_u_b_mw.log).
-__device__ __forceinline__ int sparse_wgs_pp_ordinary_end(const PlanArgs& a) { return a.sparse_wgs_pp - a.tiny_wgs; }
+// (positions among the free workgroups of a panel, i.e. behind the slice_wgs XCD-bound ones; pad_wgs idle ones close the panel)
+__device__ __forceinline__ int sparse_wgs_pp_ordinary_end(const PlanArgs& a) { return a.free_wgs_pp - a.tiny_wgs; }
 
 // second-widest and narrowest dense-tile vector of a VEC-wide build
 template <int VEC> struct DenseV {
@@ -685,33 +686,55 @@ __global__ __launch_bounds__(kThreads, MINW) void hybrid_plan_kernel(PlanArgs a)
     const int b = (int)blockIdx.x - p * a.sparse_wgs_pp;
     const int c0 = p * a.panel_cols;
     const int cend = min(a.D, c0 + a.panel_cols);
-    if (b < a.wide_wgs) {
+    const int bf = b - a.slice_wgs;  // position among the free (not XCD-bound) workgroups of the panel
+    if (bf >= 0 && bf < a.wide_wgs) {
       // wide tasks: the a.n_wide longest tasks, one per wave
-      const int tid = b * kWaves + wave;
+      const int tid = bf * kWaves + wave;
       if (tid >= a.n_wide) return;
       const int4 t = reinterpret_cast<const int4*>(a.plan + a.off_tasks)[tid];
       elem_t* dz = (t.w < 0) ? Z + (size_t)t.x * a.ldz : nullptr;
       float* dp = (t.w < 0) ? nullptr : a.partial + (size_t)t.w * (size_t)a.D;
       sparse_task<E, L, VEC, true, UNROLL>(X, dz, dp, a.col, __builtin_amdgcn_readfirstlane(t.y),
                                            __builtin_amdgcn_readfirstlane(t.z), a.ldx, c0, cend, lane);
-    } else if (b >= sparse_wgs_pp_ordinary_end(a)) {
+    } else if (bf >= sparse_wgs_pp_ordinary_end(a)) {
       constexpr int R = 64 / L;
-      const int first = a.n_tasks - a.n_tiny + ((b - sparse_wgs_pp_ordinary_end(a)) * kWaves + wave) * (R * TinyT<L>::value);
+      const int first = a.n_tasks - a.n_tiny + ((bf - sparse_wgs_pp_ordinary_end(a)) * kWaves + wave) * (R * TinyT<L>::value);
       if (first >= a.n_tasks) return;
       tiny_tasks<E, L, VEC, TinyT<L>::value>(a, first, c0, cend, lane);
     } else {
+      // ordinary tasks, and the XCD-affine sliced ones: R per wave, one lane group each, strictly in CSR order
       constexpr int R = 64 / L;
       const int g = lane / L;
-      const int tid = a.n_wide + ((b - a.wide_wgs) * kWaves + wave) * R + g;
+      const int4* tp = nullptr;
+      if (bf < 0) {
+        // sliced region: workgroup b serves the slices s = b (mod 8) -- all workgroups that share its XCD's L2 gather from
+        // the same 1/8 of the X rows.  The slice lists are padded to whole waves (64 descriptors), so a wave never straddles
+        // two lists; padding descriptors have row -1.
+        cint_p tbl = (cint_p)(a.plan + a.off_slice_table);  // wave-uniform: scalar loads
+        int j = ((b >> 3) * kWaves + wave) * R;             // first descriptor of this wave in its XCD's concatenated lists
+        for (int sl = b & 7; sl < a.n_slices; sl += 8) {
+          const int lo = tbl[sl], cnt = tbl[sl + 1] - lo;
+          if (j < cnt) {
+            tp = reinterpret_cast<const int4*>(a.plan + a.off_slice_tasks) + lo + j + g;
+            break;
+          }
+          j -= cnt;
+        }
+      } else {
+        const int tid = a.n_wide + ((bf - a.wide_wgs) * kWaves + wave) * R + g;
+        if (tid < a.n_tasks - a.n_tiny) tp = reinterpret_cast<const int4*>(a.plan + a.off_tasks) + tid;
+      }
       int e0 = 0, n = 0;
       elem_t* dz = nullptr;
       float* dp = nullptr;
-      if (tid < a.n_tasks - a.n_tiny) {
-        const int4 t = reinterpret_cast<const int4*>(a.plan + a.off_tasks)[tid];
-        e0 = t.y;
-        n = t.z;
-        if (t.w < 0) dz = Z + (size_t)t.x * a.ldz;
-        else dp = a.partial + (size_t)t.w * (size_t)a.D;
+      if (tp != nullptr) {
+        const int4 t = *tp;
+        if (t.x >= 0) {
+          e0 = t.y;
+          n = t.z;
+          if (t.w < 0) dz = Z + (size_t)t.x * a.ldz;
+          else dp = a.partial + (size_t)t.w * (size_t)a.D;
+        }
       }
       sparse_task<E, L, VEC, false, UNROLL>(X, dz, dp, a.col, e0, n, a.ldx, c0, cend, lane);
     }
@@ -919,7 +942,12 @@ static hipError_t launch_plan_LV(const PlanArgs& a, hipStream_t stream) {
   b.n_wide = (R > 1) ? a.n_wide : 0;  // with one lane group per wave a wide task is an ordinary one
   b.wide_wgs = (b.n_wide + kWaves - 1) / kWaves;
   b.tiny_wgs = (a.n_tiny + kWaves * R * TinyT<L>::value - 1) / (kWaves * R * TinyT<L>::value);
-  b.sparse_wgs_pp = b.wide_wgs + (a.n_tasks - a.n_tiny - b.n_wide + kWaves * R - 1) / (kWaves * R) + b.tiny_wgs;
+  b.free_wgs_pp = b.wide_wgs + (a.n_tasks - a.n_tiny - b.n_wide + kWaves * R - 1) / (kWaves * R) + b.tiny_wgs;
+  // the sliced region: per XCD ceil(slice_xcd_tasks / tasks per workgroup) workgroups, interleaved b = x (mod 8); a panel is
+  // padded to a multiple of 8 workgroups so that b mod 8 == blockIdx mod 8 in every panel (the idle ones return at once)
+  b.slice_wgs = a.n_slices > 0 ? 8 * ((a.slice_xcd_tasks + kWaves * R - 1) / (kWaves * R)) : 0;
+  b.sparse_wgs_pp = b.slice_wgs + b.free_wgs_pp;
+  if (b.slice_wgs > 0) b.sparse_wgs_pp = (b.sparse_wgs_pp + 7) & ~7;
   const int n_col_panels = (a.D + a.panel_cols - 1) / a.panel_cols;
   b.sparse_wgs = b.sparse_wgs_pp * n_col_panels;
   if (b.sparse_wgs_pp == 0) b.sparse_wgs_pp = 1;  // divisor in the kernel

@@ -27,6 +27,11 @@ struct PlanArgs {
   int sparse_wgs_pp, dense_vec;        // filled by the launcher
   int wide_wgs, sparse_wgs, n_panels;  // filled by the launcher
   int tiny_wgs;                        // filled by the launcher: workgroups of the tiny-task region (per panel)
+  // XCD-affine column slices (hcspmm.h n_slices): slice s owns descriptors [table[s], table[s+1]) of the slice task
+  // list and is served by the workgroups b = s (mod 8) of the sliced region, the first slice_wgs of every panel
+  int off_slice_table, off_slice_tasks, n_slices, slice_xcd_tasks;
+  int slice_wgs;                       // filled by the launcher (a multiple of 8)
+  int free_wgs_pp;                     // filled by the launcher: wide + ordinary + tiny workgroups per panel
   // fused aggregate+update (hcspmm_forward_fused, fp32 only): when fused != 0 every dense-tile window also
   // multiplies its 16 x D tile by the weights while it is still in the MFMA accumulators and writes 16 rows of
   // out (N x H, row-major); Z is then the operator's out2.  W: D x H with element strides (w_ldr, w_ldc).

@@ -246,6 +246,7 @@ def preprocess(column_index, row_pointers, num_nodes, num_edges, num_row_windows
     check(L.hcspmm_plan_build(_ptr(rp_h), _ptr(col_h), N, E, M, _ptr(bp), _ptr(e2c), _ptr(ht),
                               ctypes.byref(_PLAN_PARAMS), _ptr(plan), plan.numel()))
     h = Header.from_buffer_copy(plan[:Header.WORDS].numpy().tobytes())
+    plan = plan[:h.total_words]  # hcspmm_plan_words sizes for the larger of the two layouts (column slices or none)
     outs = [t.to(dev, non_blocking=True) for t in (bp, e2c, e2r, ht, plan)]  # .to() is a no-op for the device-made e2r
     _register(outs[4], h, row_pointers, column_index)
     col_nzr = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -253,22 +254,24 @@ def preprocess(column_index, row_pointers, num_nodes, num_edges, num_row_windows
 
 
 def build_plan(row_pointers, column_index, blockPartition, edgeToColumn, hybrid_type, device=None,
-               split_threshold=0, segment_len=0, num_columns=None, fuse_in_launch=False):
+               split_threshold=0, segment_len=0, num_columns=None, fuse_in_launch=False, slice_threshold=0, n_slices=0):
     """Launch plan for an arbitrary window classification (e.g. every window forced onto one sub-path,
     or a classifier of the caller's own): -> plan tensor to pass as `row_nzr`.  fuse_in_launch: the fused
-    operators update this plan's dense-tile windows inside the hybrid launch (include/hcspmm.h hcspmm_forward_fused)."""
+    operators update this plan's dense-tile windows inside the hybrid launch (include/hcspmm.h hcspmm_forward_fused).
+    slice_threshold / n_slices: XCD-affine column slices (hcspmm_plan_params; 0 = automatic, < 0 = off)."""
     L = lib()
     rp_h, col_h = _i32_host(row_pointers), _i32_host(column_index)
     bp_h, e2c_h, ht_h = _i32_host(blockPartition), _i32_host(edgeToColumn), _i32_host(hybrid_type)
     N, E = rp_h.numel() - 1, col_h.numel()
-    params = PlanParams(int(split_threshold), int(segment_len), int(bool(fuse_in_launch))) \
-        if (split_threshold or segment_len or fuse_in_launch) else _PLAN_PARAMS
+    params = PlanParams(int(split_threshold), int(segment_len), int(bool(fuse_in_launch)), int(slice_threshold), int(n_slices)) \
+        if (split_threshold or segment_len or fuse_in_launch or slice_threshold or n_slices) else _PLAN_PARAMS
     words = ctypes.c_int64(0)
     check(L.hcspmm_plan_words(_ptr(rp_h), N, E, _ptr(bp_h), _ptr(ht_h), ctypes.byref(params), ctypes.byref(words)))
     plan = torch.empty(max(int(words.value), Header.WORDS), dtype=torch.int32)
     check(L.hcspmm_plan_build(_ptr(rp_h), _ptr(col_h), N, E, N if num_columns is None else int(num_columns), _ptr(bp_h),
                               _ptr(e2c_h), _ptr(ht_h), ctypes.byref(params), _ptr(plan), plan.numel()))
     h = Header.from_buffer_copy(plan[:Header.WORDS].numpy().tobytes())
+    plan = plan[:h.total_words]
     dev = torch.device(device) if device is not None else row_pointers.device
     plan_d = plan.to(dev)
     _register(plan_d, h, row_pointers, column_index)

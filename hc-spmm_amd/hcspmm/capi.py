@@ -28,7 +28,12 @@ class Header(ctypes.Structure):
                                                                                   ("off_dense_compact2", ctypes.c_int32), ("num_columns", ctypes.c_int32),
                                                                                   ("n_sparse_windows", ctypes.c_int32), ("off_sparse_windows", ctypes.c_int32),
                                                                                   ("fingerprint_lo", ctypes.c_uint32), ("fingerprint_hi", ctypes.c_uint32),
-                                                                                  ("dense_k_sum", ctypes.c_int32), ("flags", ctypes.c_int32), ("reserved", ctypes.c_int32 * 27)]
+                                                                                  ("dense_k_sum", ctypes.c_int32), ("flags", ctypes.c_int32),
+                                                                                  ("n_slices", ctypes.c_int32), ("slice_threshold", ctypes.c_int32),
+                                                                                  ("off_slice_table", ctypes.c_int32), ("off_slice_tasks", ctypes.c_int32),
+                                                                                  ("n_slice_tasks", ctypes.c_int32), ("slice_xcd_tasks", ctypes.c_int32),
+                                                                                  ("nnz_sliced", ctypes.c_int32), ("n_sliced_rows", ctypes.c_int32),
+                                                                                  ("reserved", ctypes.c_int32 * 19)]
 
     @property
     def fingerprint(self):
@@ -37,7 +42,8 @@ class Header(ctypes.Structure):
 
 class PlanParams(ctypes.Structure):
     """hcspmm_plan_params."""
-    _fields_ = [("split_threshold", ctypes.c_int32), ("segment_len", ctypes.c_int32), ("fuse_in_launch", ctypes.c_int32)]
+    _fields_ = [("split_threshold", ctypes.c_int32), ("segment_len", ctypes.c_int32), ("fuse_in_launch", ctypes.c_int32),
+                ("slice_threshold", ctypes.c_int32), ("n_slices", ctypes.c_int32)]
 
 
 # every exported symbol of include/hcspmm.h: name -> (restype, argtypes)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HCSPMM_ABI_VERSION 2
+#define HCSPMM_ABI_VERSION 3
 
 /* Row-window geometry: hybrid_kernel/config.h:4-5 (BLK_H 16, BLK_W 8). */
 #define HCSPMM_BLK_H 16
@@ -96,7 +96,7 @@ int hcspmm_edge_to_row_device(const int32_t* row_pointers_d, int64_t num_nodes, 
  * read-back).
  * ---------------------------------------------------------------------------------------- */
 #define HCSPMM_PLAN_MAGIC 0x48435350 /* "HCSP" */
-#define HCSPMM_PLAN_VERSION 6
+#define HCSPMM_PLAN_VERSION 7
 #define HCSPMM_TINY_LEN 2 /* tasks of at most this many entries carry their indices in the descriptor */
 #define HCSPMM_COMPACT_K 40     /* dense windows of at most this many (padded) columns use compact records ... */
 #define HCSPMM_COMPACT_WORDS 64 /* ... of this many words: [window, K/4, U[40], 10 x (mask lo, mask hi), pad] */
@@ -146,7 +146,21 @@ typedef struct hcspmm_plan_header {
                                dense-tile path executes exactly 2*16*K*D flop per window */
   int32_t flags;            /* HCSPMM_PLAN_FUSE_IN_LAUNCH: the fused operators update this plan's dense-tile windows inside the
                                hybrid launch (hcspmm_plan_params.fuse_in_launch) */
-  int32_t reserved[27];
+  /* XCD-affine column slices: sparse-path rows longer than slice_threshold are cut where their
+   * (ascending) column ids cross n_slices - 1 boundaries and every segment_len entries; the pieces of slice s form
+   * their own task list, served only by workgroups with blockIdx % 8 == s % 8 -- workgroups that share one of the
+   * eight per-XCD L2s -- so that L2 holds 1/8 of the X rows those tasks gather.  Placement is a speed matter only. */
+  int32_t n_slices;         /* 0: none; else a multiple of 8 */
+  int32_t slice_threshold;  /* rows with more entries than this are sliced (when n_slices > 0) */
+  int32_t off_slice_table;  /* n_slices + 1 task offsets relative to off_slice_tasks, each a multiple of 64: slice s
+                               owns descriptors [table[s], table[s+1]), longest length class first, padded with
+                               (-1, 0, 0, -1) */
+  int32_t off_slice_tasks;  /* descriptors (row, first entry, length, partial slot or -1), as the ordinary tasks */
+  int32_t n_slice_tasks;    /* = table[n_slices], padding included */
+  int32_t slice_xcd_tasks;  /* max over x in [0, 8) of the descriptors of the slices s = x (mod 8): sizes the region */
+  int32_t nnz_sliced;       /* entries covered by sliced tasks (part of nnz_sparse) */
+  int32_t n_sliced_rows;
+  int32_t reserved[19];
 } hcspmm_plan_header;
 
 #define HCSPMM_PLAN_FUSE_IN_LAUNCH 1
@@ -158,6 +172,10 @@ typedef struct hcspmm_plan_params {
   int32_t fuse_in_launch;  /* != 0: hcspmm_forward_fused multiplies the dense-tile windows by the weights inside the
                               hybrid launch (see there).  Default 0: measured on MI355X the two-launch form is 0-8 % faster
                               (profiles/r02/ab_fused.log) */
+  int32_t slice_threshold; /* XCD-affine column slices: 0 = automatic (on for num_columns >= 65536 when at least 5 % of
+                              the sparse-path entries sit in rows longer than 64 entries; HCSPMM_SLICE_THRESHOLD in the
+                              environment overrides), > 0: rows longer than this are sliced, < 0: off */
+  int32_t n_slices;        /* 0 = 8 (HCSPMM_SLICES overrides); rounded up to a multiple of 8, at most 64 */
 } hcspmm_plan_params;
 
 /* Number of int32 words a plan for this graph needs (so the caller can allocate the tensor). */

@@ -40,9 +40,11 @@ class CtypesFrontend:
     def preprocess(self, col_d, rp_d, N, E, W, rule=0, num_columns=None):
         return self.m.preprocess(col_d, rp_d, N, E, W, rule=rule, num_columns=num_columns)
 
-    def build_plan(self, rp_d, col_d, bp, e2c, ht, split_threshold=0, segment_len=0, num_columns=None, fuse_in_launch=False):
+    def build_plan(self, rp_d, col_d, bp, e2c, ht, split_threshold=0, segment_len=0, num_columns=None, fuse_in_launch=False,
+                   slice_threshold=0, n_slices=0):
         return self.m.build_plan(rp_d, col_d, bp, e2c, ht, split_threshold=split_threshold, segment_len=segment_len,
-                                 num_columns=num_columns, fuse_in_launch=fuse_in_launch)
+                                 num_columns=num_columns, fuse_in_launch=fuse_in_launch, slice_threshold=slice_threshold,
+                                 n_slices=n_slices)
 
     def header(self, row_nzr):
         return self.m.plan_header(row_nzr)
@@ -70,9 +72,11 @@ class ExtensionFrontend:
         finally:
             self.m.set_rule(0)
 
-    def build_plan(self, rp_d, col_d, bp, e2c, ht, split_threshold=0, segment_len=0, num_columns=None, fuse_in_launch=False):
+    def build_plan(self, rp_d, col_d, bp, e2c, ht, split_threshold=0, segment_len=0, num_columns=None, fuse_in_launch=False,
+                   slice_threshold=0, n_slices=0):
         return self.m.build_plan(rp_d, col_d, bp, e2c, ht, int(split_threshold), int(segment_len),
-                                 -1 if num_columns is None else int(num_columns), bool(fuse_in_launch))
+                                 -1 if num_columns is None else int(num_columns), bool(fuse_in_launch), int(slice_threshold),
+                                 int(n_slices))
 
     def header(self, row_nzr):
         info = self.m.plan_info(row_nzr)

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(capi):
     L = capi.lib()
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.hcspmm_abi_version() == 2
+    assert L.hcspmm_abi_version() == 3
     assert ctypes.sizeof(Header) == 4 * Header.WORDS
 
 
@@ -153,6 +153,35 @@ def _decode_plan(plan):
     return h, tasks, dindex, fix
 
 
+def _decode_slices(plan, h):
+    """XCD-affine column slices: -> (table, [descriptors of slice s without the padding]) after checking the layout
+    (offsets multiples of 64, padding = (-1, 0, 0, -1) at the end of every list, longest length class first, rows
+    ascending inside a class)."""
+    if h.n_slices == 0:
+        assert h.n_slice_tasks == 0 and h.slice_xcd_tasks == 0 and h.nnz_sliced == 0
+        return np.zeros(1, np.int64), []
+    table = plan[h.off_slice_table:h.off_slice_table + h.n_slices + 1].astype(np.int64)
+    assert table[0] == 0 and table[-1] == h.n_slice_tasks and np.all(np.diff(table) >= 0) and np.all(table % 64 == 0)
+    per_xcd = [int(sum(table[s + 1] - table[s] for s in range(x, h.n_slices, 8))) for x in range(8)]
+    assert h.slice_xcd_tasks == max(per_xcd)
+    desc = plan[h.off_slice_tasks:h.off_slice_tasks + 4 * h.n_slice_tasks].reshape(-1, 4)
+    out = []
+    for s in range(h.n_slices):
+        d = desc[table[s]:table[s + 1]]
+        real = d[:, 0] >= 0
+        n = int(real.sum())
+        assert np.all(real[:n]) and np.all(d[n:] == np.array([-1, 0, 0, -1])) and len(d) - n < 64
+        d = d[:n]
+        lens = d[:, 2]
+        assert np.all(lens >= 1) and np.all(lens <= h.segment_len)
+        cls = np.ceil(np.log2(np.maximum(lens, 1))).astype(int) + 1
+        assert np.all(np.diff(cls) <= 0)
+        for c in np.unique(cls):
+            assert np.all(np.diff(d[cls == c, 0]) >= 0)
+        out.append(d)
+    return table, out
+
+
 def _expand_tiny(h, tasks, fix, rp, col):
     """The last n_tiny descriptors are (row | -(slot+1), index0, length, index1): turn them back into
     (row, e0, length, slot) after checking the inline indices against the CSR arrays."""
@@ -202,7 +231,7 @@ def test_plan_covers_every_entry_exactly_once(name, gen):
     plan = plan_t.numpy()
     h, tasks, dindex, fix = _decode_plan(plan)
     tasks = _expand_tiny(h, tasks, fix, rp, col)
-    assert h.magic == Header.MAGIC and h.num_nodes == N and h.num_edges == E and h.total_words == len(plan)
+    assert h.magic == Header.MAGIC and h.num_nodes == N and h.num_edges == E and h.total_words <= len(plan)
     ht = ht.numpy()
     cover = np.zeros(E, np.int32)
     rows_written = np.zeros(N, np.int32)
@@ -556,3 +585,65 @@ def test_preprocess_frozen_fixture(oracle_mod, name):
             assert np.array_equal(got[0], g["%s_rule%d_blockPartition" % (name, rule)])
             assert np.array_equal(got[3], g["%s_rule%d_hybrid_type" % (name, rule)])
             assert np.array_equal(got[1], g[name + "_edgeToColumn"]) and np.array_equal(got[2], g[name + "_edgeToRow"])
+
+
+def test_plan_column_slices_layout():
+    """hcspmm_plan_params.slice_threshold / n_slices: rows longer than the threshold are cut at column-slice boundaries;
+    every slice's pieces lie in its own column range, the ranges ascend with the slice number, a row's pieces take
+    consecutive partial slots in CSR order, and every entry is covered exactly once."""
+    rp, col = graphs.powerlaw_graph(3000, 90000, seed=5, max_degree_frac=0.3)
+    N, E = len(rp) - 1, len(col)
+    bp, e2c, e2r, ht, _, _ = _pre(rp, col, 2)
+    for S, thr, seg in ((8, 16, 0), (16, 40, 32), (8, 1, 0)):
+        plan = hcspmm.build_plan(torch.from_numpy(rp), torch.from_numpy(col), bp, e2c, ht, slice_threshold=thr, n_slices=S,
+                                 segment_len=seg, split_threshold=max(seg, 0) * 2).numpy()
+        h, tasks, _, fix = _decode_plan(plan)
+        assert h.n_slices == S and h.slice_threshold == thr and h.total_words == len(plan)
+        assert hcspmm.capi.lib().hcspmm_plan_check(ctypes.byref(h), N, E, len(plan)) == 0
+        table, slices = _decode_slices(plan, h)
+        deg = np.diff(rp)
+        assert h.n_sliced_rows == int((deg > thr).sum()) and h.nnz_sliced == int(deg[deg > thr].sum())
+        cover = np.zeros(E, np.int32)
+        free = _expand_tiny(h, tasks, fix, rp, col)
+        for row, e0, ln, slot in free:
+            assert deg[row] <= thr
+            cover[e0:e0 + ln] += 1
+        lo_hi = []
+        pieces = {}
+        for s, d in enumerate(slices):
+            if len(d):
+                lo_hi.append((int(col[d[:, 1]].min()), int(col[d[:, 1] + d[:, 2] - 1].max())))
+            for row, e0, ln, slot in d:
+                assert deg[row] > thr and rp[row] <= e0 and e0 + ln <= rp[row + 1]
+                cover[e0:e0 + ln] += 1
+                pieces.setdefault(int(row), []).append((int(e0), int(ln), int(slot)))
+        assert np.all(cover == 1)
+        assert all(a[1] < b[0] for a, b in zip(lo_hi, lo_hi[1:]))  # the slices' column ranges ascend and do not overlap
+        fixmap = {int(r): (int(s0), int(ns)) for r, s0, ns, _ in fix}
+        n_slots = 0
+        for row, ps in pieces.items():
+            ps.sort()
+            if len(ps) == 1:
+                assert ps[0][2] == -1 and row not in fixmap
+                continue
+            s0, ns = fixmap[row]
+            assert ns == len(ps) and [p[2] for p in ps] == list(range(s0, s0 + ns))  # slot order = CSR order
+            n_slots += ns
+        assert h.n_partials == n_slots and h.n_split_rows == len(fixmap)
+    # off: no slice sections, the round-2 layout
+    plan = hcspmm.build_plan(torch.from_numpy(rp), torch.from_numpy(col), bp, e2c, ht, slice_threshold=-1).numpy()
+    h = _decode_plan(plan)[0]
+    assert h.n_slices == 0 and h.n_slice_tasks == 0 and h.total_words == len(plan)
+
+
+def test_plan_column_slices_automatic_rule():
+    """Automatic mode: on only when X spans many L2s (num_columns >= 65536) and the long rows hold >= 5 % of the entries."""
+    rp, col = graphs.powerlaw_graph(3000, 90000, seed=5, max_degree_frac=0.3)
+    bp, e2c, e2r, ht, plan, _ = _pre(rp, col, 2)
+    assert _decode_plan(plan.numpy())[0].n_slices == 0  # 3000 columns
+    plan = hcspmm.build_plan(torch.from_numpy(rp), torch.from_numpy(col), bp, e2c, ht, num_columns=70000).numpy()
+    h = _decode_plan(plan)[0]
+    assert h.n_slices == 8 and h.slice_threshold == 64 and h.total_words == len(plan)
+    rp2, col2 = graphs.uniform_graph(3000, 30000, seed=1)  # no long rows
+    bp, e2c, e2r, ht, _, _ = _pre(rp2, col2, 2)
+    assert _decode_plan(hcspmm.build_plan(torch.from_numpy(rp2), torch.from_numpy(col2), bp, e2c, ht, num_columns=70000).numpy())[0].n_slices == 0

@@ -63,6 +63,13 @@ class Graph:
         return (fn or self.fe.forward)(X, *self.args())[0]
 
 
+def _seq_limit(h, wide_thr):
+    """Rows of at most this many entries are summed strictly in CSR order by one lane group: not split into segments,
+    not handed to a whole wave, not cut into XCD-affine column slices."""
+    lim = min(h.split_threshold, wide_thr)
+    return min(lim, h.slice_threshold) if h.n_slices else lim
+
+
 def _check(oracle_mod, g, X_np, Z, exact_bits=None):
     """Tolerance for every element; bit-identity with the CSR-order fp32 oracle for every row that one
     lane group (or one dense-tile MFMA chain) sums sequentially: all rows on the plan-free kernel,
@@ -79,7 +86,7 @@ def _check(oracle_mod, g, X_np, Z, exact_bits=None):
         seq = deg <= g.fe.wide_threshold(g.row_nzr, D)
         seq |= np.repeat(g.ht.cpu().numpy() != 0, 16)[:g.N]
     else:
-        seq = deg <= min(h.split_threshold, g.fe.wide_threshold(g.row_nzr, D))
+        seq = deg <= _seq_limit(h, g.fe.wide_threshold(g.row_nzr, D))
         seq |= np.repeat(g.ht.cpu().numpy() != 0, 16)[:g.N]
     assert np.array_equal(Z[seq], ref[seq]), "sequentially-summed rows differ from the CSR-order fp32 oracle"
     if exact_bits:
@@ -190,6 +197,34 @@ def test_split_rows_are_deterministic_and_within_tolerance(oracle_mod, dev, fe):
     _check(oracle_mod, g, X, Z1)  # includes: short rows still bit-identical to the sequential oracle
 
 
+@pytest.mark.parametrize("name,gen,split_free", CASES[:4], ids=[c[0] for c in CASES[:4]])
+@pytest.mark.parametrize("D", [32, 128, 22, 300])
+@pytest.mark.parametrize("slices", [(8, 8, 0), (16, 3, 4), (8, 1, 0), (24, 40, 16)], ids=lambda v: "S%d_thr%d_seg%d" % v)
+def test_column_slices_parity(oracle_mod, dev, fe, name, gen, split_free, D, slices):
+    """XCD-affine column slices forced on small graphs (hcspmm_plan_params.slice_threshold / n_slices; automatic only
+    from 65536 columns): rows above the threshold are summed piecewise (1e-5 bar, exact on integer X, run-to-run
+    deterministic), rows at or below it keep the CSR-order bits; the result does not depend on which XCD serves a slice."""
+    S, thr, seg = slices
+    rp, col = gen()
+    g = Graph(rp, col, dev, fe=fe)
+    g.row_nzr = fe.build_plan(g.rp_d, g.col_d, g.bp, g.e2c, g.ht, slice_threshold=thr, n_slices=S, segment_len=seg,
+                              split_threshold=2 * seg)
+    h = g.header()
+    deg = np.diff(rp)
+    sparse_rows = np.repeat(g.ht.cpu().numpy() == 0, 16)[:g.N]
+    assert h.n_slices == S and h.n_sliced_rows == int(((deg > thr) & sparse_rows).sum())
+    X = np.random.default_rng(D + S).standard_normal((g.N, D)).astype(np.float32)
+    Xd = _t(X, dev)
+    Z = g.forward(Xd)
+    _check(oracle_mod, g, X, Z)
+    assert torch.equal(Z, g.forward(Xd))
+    Xi = np.tile((np.arange(g.N, dtype=np.float32) % 4093)[:, None], (1, D))
+    assert np.array_equal(g.forward(_t(Xi, dev)).cpu().numpy(), oracle_mod.spmm_f32(rp, col, Xi))
+    if D == 128:  # 16-bit features through the same sliced plan
+        X16 = Xd.to(torch.bfloat16)
+        _check_h16(oracle_mod, g, X16, g.forward(X16))
+
+
 @pytest.mark.parametrize("D", [128, 64, 32, 17, 4])
 def test_dense_windows_around_the_compact_record_limit(oracle_mod, dev, fe, D):
     """Dense windows with exactly K = 1 ... 40 (compact 64-word records), 41 ... 80 (128-word records) and 81, 96,
@@ -257,7 +292,7 @@ def _check_h16(oracle_mod, g, X16, Z16):
     h = g.header()
     deg = np.diff(g.rp)
     thr = g.fe.wide_threshold(g.row_nzr, D, dtype)
-    seq = deg <= (thr if h is None else min(h.split_threshold, thr))
+    seq = deg <= (thr if h is None else _seq_limit(h, thr))
     seq |= np.repeat(g.ht.cpu().numpy() != 0, 16)[:g.N]
     got = Z16.cpu()
     assert torch.equal(got[torch.from_numpy(seq)].view(torch.int16), want[torch.from_numpy(seq)].view(torch.int16))

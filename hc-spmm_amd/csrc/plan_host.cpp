@@ -49,7 +49,7 @@
 namespace {
 
 constexpr int kSliceAuto = 0, kSliceOn = 1, kSliceOff = -1;
-constexpr int32_t kSliceAutoThreshold = 64;       // rows longer than this are sliced (tools/l2_hit_simulation.py, profiles/r03/ab_slices.log)
+constexpr int32_t kSliceAutoThreshold = 256;      // rows longer than this are sliced: flat optimum 192-256 on every workload (profiles/r03/ab_slices.log)
 constexpr int64_t kSliceAutoMinColumns = 65536;  // a 128-byte line per X row: below this a panel of X is within two L2s anyway
 constexpr int kSlicePad = 64;                    // slice lists are padded to whole waves of any lane-group count (4 waves x 16)
 

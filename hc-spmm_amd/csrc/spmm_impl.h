@@ -686,7 +686,10 @@ __global__ __launch_bounds__(kThreads, MINW) void hybrid_plan_kernel(PlanArgs a)
     const int b = (int)blockIdx.x - p * a.sparse_wgs_pp;
     const int c0 = p * a.panel_cols;
     const int cend = min(a.D, c0 + a.panel_cols);
-    const int bf = b - a.slice_wgs;  // position among the free (not XCD-bound) workgroups of the panel
+    // position among the free (not XCD-bound) workgroups of the panel; < 0: one of the XCD-bound ones in front of them.
+    // (Alternating groups of sliced and free workgroups, so that L2-bound and fabric-bound work overlap, was built and
+    // measured: 0-4 % slower everywhere -- the free tasks' lines evict the slice's: profiles/r03/ab_slice_interleave.log.)
+    const int bf = b - a.slice_wgs;
     if (bf >= 0 && bf < a.wide_wgs) {
       // wide tasks: the a.n_wide longest tasks, one per wave
       const int tid = bf * kWaves + wave;

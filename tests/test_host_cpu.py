@@ -643,7 +643,7 @@ def test_plan_column_slices_automatic_rule():
     assert _decode_plan(plan.numpy())[0].n_slices == 0  # 3000 columns
     plan = hcspmm.build_plan(torch.from_numpy(rp), torch.from_numpy(col), bp, e2c, ht, num_columns=70000).numpy()
     h = _decode_plan(plan)[0]
-    assert h.n_slices == 8 and h.slice_threshold == 64 and h.total_words == len(plan)
+    assert h.n_slices == 8 and h.slice_threshold == 256 and h.total_words == len(plan)
     rp2, col2 = graphs.uniform_graph(3000, 30000, seed=1)  # no long rows
     bp, e2c, e2r, ht, _, _ = _pre(rp2, col2, 2)
     assert _decode_plan(hcspmm.build_plan(torch.from_numpy(rp2), torch.from_numpy(col2), bp, e2c, ht, num_columns=70000).numpy())[0].n_slices == 0

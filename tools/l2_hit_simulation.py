@@ -49,7 +49,7 @@ def class_order(row, ln):
     return np.lexsort((row, -length_class(ln)))
 
 
-def build_schedule(rp, col, n_cols, thr, S, seg=256, split=512, tasks_per_wg=32, n_xcd=8):
+def build_schedule(rp, col, n_cols, thr, S, seg=256, split=512, tasks_per_wg=32, n_xcd=8, interleave=False):
     """-> per-XCD (e0, len, kind, wg_start) + statistics.  thr <= 0: the round-2 schedule (rows > split cut every seg entries)."""
     N = len(rp) - 1
     deg = np.diff(rp).astype(np.int64)
@@ -118,6 +118,20 @@ def build_schedule(rp, col, n_cols, thr, S, seg=256, split=512, tasks_per_wg=32,
         ln = np.concatenate([ln, fln]).astype(np.int32)
         kd = np.concatenate([kd, np.zeros(len(fe0), np.int8)])
         wg_start = np.array(starts + list(fst), dtype=np.int64)
+        if interleave and n_sl_wg and len(wgs):
+            # sliced and free workgroups alternate in proportion (both resources -- L2 hits and fabric misses -- busy at once)
+            n_a, n_b = n_sl_wg, len(wgs)
+            pos_a = (np.arange(n_a) + 0.5) / n_a
+            pos_b = (np.arange(n_b) + 0.5) / n_b
+            order = np.argsort(np.concatenate([pos_a, pos_b]), kind="stable")
+            sizes = np.diff(wg_start)
+            new_e0, new_ln, new_kd, new_start = [], [], [], [0]
+            for w in order:
+                a, b = wg_start[w], wg_start[w + 1]
+                new_e0.append(e0[a:b]); new_ln.append(ln[a:b]); new_kd.append(kd[a:b])
+                new_start.append(new_start[-1] + (b - a))
+            e0, ln, kd = np.concatenate(new_e0), np.concatenate(new_ln), np.concatenate(new_kd)
+            wg_start = np.array(new_start, dtype=np.int64)
         out.append((e0, ln, kd, wg_start))
     stats["xcd_nnz"] = [int(o[1].sum()) for o in out]
     return out, stats
@@ -141,6 +155,7 @@ def main():
     ap.add_argument("--lines", type=int, default=32768)
     ap.add_argument("--conc", type=int, default=160)
     ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--interleave", action="store_true", help="sliced and free workgroups alternate instead of sliced first")
     args = ap.parse_args()
     sys.path.insert(0, R)
     import bench
@@ -154,7 +169,7 @@ def main():
     for thr in [int(t) for t in args.thresholds.split(",")]:
         for S in ([0] if thr <= 0 else [int(s) for s in args.slices.split(",")]):
             t0 = time.time()
-            sched, st = build_schedule(rp, col, n_cols, thr, S)
+            sched, st = build_schedule(rp, col, n_cols, thr, S, interleave=args.interleave)
             hits, tot = simulate(lib, col, n_cols, sched, args.lines, args.conc)
             miss = (tot - hits).sum()
             traffic = panels * (miss * 128 + st["n_partials"] * 128 * 2 + N * 128) + 4 * E * panels + 4 * (N + 1)

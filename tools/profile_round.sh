@@ -4,7 +4,7 @@
 # Passes are separate runs (kernel trace + stats; then one PMC set per run), as MI355X_MICROARCH.md
 # prescribes.  Summarise afterwards with profiles/summarize.py.
 export TMPDIR=/tmp
-OUT=gpurun_out/prof_round
+OUT=${PROF_OUT:-gpurun_out/prof_round}   # PROF_OUT / SKIP_MFMA=1: A/B runs of variants selected through the environment
 mkdir -p $OUT
 run() {  # name, bench args...
   name=$1; shift
@@ -13,7 +13,7 @@ run() {  # name, bench args...
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/$name/fetch -- python3 bench.py "$@" --steps 10 --warmup 2 --no-cpu-baseline --no-pmc --no-sweep > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/$name/write -- python3 bench.py "$@" --steps 10 --warmup 2 --no-cpu-baseline --no-pmc --no-sweep > /dev/null 2>&1
   rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/$name/l2 -- python3 bench.py "$@" --steps 10 --warmup 2 --no-cpu-baseline --no-pmc --no-sweep > /dev/null 2>&1
-  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/$name/mfma -- python3 bench.py "$@" --steps 10 --warmup 2 --no-cpu-baseline --no-pmc --no-sweep > /dev/null 2>&1
+  [ -n "$SKIP_MFMA" ] || rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/$name/mfma -- python3 bench.py "$@" --steps 10 --warmup 2 --no-cpu-baseline --no-pmc --no-sweep > /dev/null 2>&1
   rm -rf /tmp/hcspmm_graph_$name
   echo "$name done"
 }

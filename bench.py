@@ -6,9 +6,13 @@
 A "step" is one pass of the hot path, Z = A*X, over one synthetic batch (graph + embedding matrix)
 already resident in HBM.  N = 1 runs BASELINE.json config 3, "Reddit-scale": 233 000 nodes /
 11.6 M stored entries, power-law, dim 128 (the configuration the metric "dim=128" is quoted on that
-fits one GPU).  N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL) is weak scaling:
-every rank owns one such row block (columns span all N*233 000 vertices) and each step all-gathers
-the embedding row blocks over xGMI before its local product -- the one exchange step the path has.
+fits one GPU).  N > 1 -- one rank per GPU over RCCL; `python bench.py --gpus N` starts its N ranks itself
+(fresh child processes, before anything touches a GPU), `python -m torch.distributed.run ... bench.py --gpus N`
+works as well -- is weak scaling: every rank owns one such row block (columns span all N*233 000 vertices)
+and each step all-gathers the embedding row blocks over xGMI before its local product -- the one exchange
+step the path has.  `--workload products | powerlaw16m | c5` are the STRONG-scaling spellings of BASELINE
+configs 4 and 5: the same full graph (2.45 M / 62 M, 16 M / 256 M) at every N, its rows split over the ranks
+in nnz-balanced, window-aligned blocks.
 
 Prints ONE JSON line on rank 0 (contract in the task description).  At N = 1 the same line carries
   * `roofline`: live HIP-event kernel time, and -- measured by THIS run -- the bytes that crossed the fabric
@@ -19,7 +23,8 @@ Prints ONE JSON line on rank 0 (contract in the task description).  At N = 1 the
     is used and labelled with its source; failing that, the compulsory-bytes fraction.
   * `sweep`: the other BASELINE points timed in the same process -- Reddit-scale at dim 32 and 256, the
     Cora-scale config 2, one GPU's share of config 4 (dim 256) and one GPU's share of config 5 as SURVEY.md 8(d)
-    defines it (planted <= 24-column groups over 16 M columns: most windows on the dense-tile / MFMA path);
+    defines it (planted <= 24-column groups over 16 M columns: most windows on the dense-tile / MFMA path) -- each
+    with ITS counters from the same child passes (one rocprofv3 run per counter set covers every workload);
   * `cpu_baseline`: torch.sparse.mm on the box's host cores (threads stated), the oracle port nested beside it.
 """
 import argparse
@@ -61,6 +66,20 @@ WORKLOADS = {
     "dense": (2000000, 0, 128, 1, "2 M-node square graph, 70 % planted windows of 20 columns + 16 random entries per other row (round-1 dense-heavy proxy)"),
 }
 
+# Strong-scaling spellings of BASELINE configs 4 and 5: name -> (total nodes, total stored entries, dim, description).
+# The graph is the concatenation of STRONG_CHUNKS row chunks of equal height and equal entry count, chunk c generated from
+# (seed, c) alone: every world size that divides STRONG_CHUNKS sees the SAME graph, and the contiguous chunk ranges are
+# the nnz-balanced, window-aligned blocks hcspmm.sharded.partition_rows cuts it into -- exactly for the power-law graphs,
+# to within a row window or two for the planted one (tests/test_bench_cpu.py).
+STRONG_CHUNKS = 64
+STRONG_WORKLOADS = {
+    "products": (38288 * 64, 968750 * 64, 256, "BASELINE config 4 at full size (ogbn-products scale: 2.45 M nodes / 62 M entries, power-law), rows split over the ranks"),
+    "powerlaw16m": (250000 * 64, 4000000 * 64, 128, "16 M-node / 256 M-entry power-law graph without planted groups (all sparse-row), rows split over the ranks"),
+    "c5": (250000 * 64, 4000000 * 64, 128, "BASELINE config 5 at full size (16 M nodes / 256 M entries; 70 % of the 16-row windows planted groups sharing 8-24 "
+                                           "columns: dense-tile path under the reference's classifier), rows split over the ranks"),
+}
+SWEEP_PLAN = [("reddit", 32), ("reddit", 256), ("cora", 32), ("products_share", 256), ("c5_share", 128)]
+
 KERNEL_SOURCES = ["hc-spmm_amd/csrc/spmm_impl.h", "hc-spmm_amd/csrc/spmm_kernels.h", "hc-spmm_amd/csrc/capi.hip",
                   "hc-spmm_amd/csrc/plan_host.cpp", "hc-spmm_amd/csrc/preprocess_host.cpp", "include/hcspmm.h"]
 
@@ -87,6 +106,32 @@ def make_local_block(workload, n_local, e_local, world, rank, seed=3):
             return graphs.molecule_graph(n_local, seed=seed)
         return graphs.powerlaw_graph(n_local, e_local, seed=seed)
     return graphs.powerlaw_block(n_local, n_local * world, e_local, seed=seed, rank=rank)
+
+
+def make_strong_block(workload, world, rank, seed=3, chunks=STRONG_CHUNKS, scale=1):
+    """Rows [rank, rank + 1) * N / world of the strong-scaling graph `workload` (columns global): the concatenation of this
+    rank's chunks.  scale > 1 shrinks the graph (tests).  -> (row_pointers, column_index, n_local, n_total)."""
+    from hcspmm import graphs
+    n_total, e_total, _, _ = STRONG_WORKLOADS[workload]
+    if chunks % world != 0:
+        raise SystemExit("bench.py: --workload %s splits %d row chunks: --gpus must divide that (1, 2, 4, 8, ...)" % (workload, chunks))
+    n_chunk, e_chunk = n_total // chunks // scale // 16 * 16, e_total // chunks // scale
+    n_total = n_chunk * chunks
+    per = chunks // world
+    rps, cols, base = [np.zeros(1, np.int64)], [], 0
+    t_last = time.time()
+    for c in range(rank * per, (rank + 1) * per):
+        if rank == 0 and time.time() - t_last > 30.0:  # the 16 M-node graph takes minutes on one rank: say that the run is alive
+            print("bench.py: generating %s, row chunk %d of %d" % (workload, c - rank * per, per), file=sys.stderr, flush=True)
+            t_last = time.time()
+        if workload == "c5":
+            rp, col = graphs.planted_powerlaw_block(n_chunk, n_total, e_chunk, seed=seed, rank=c)
+        else:
+            rp, col = graphs.powerlaw_block(n_chunk, n_total, e_chunk, seed=seed, rank=c)
+        rps.append(rp[1:].astype(np.int64) + base)
+        cols.append(col)
+        base += int(rp[-1])
+    return np.concatenate(rps).astype(np.int32), np.concatenate(cols).astype(np.int32), n_chunk * per, n_total
 
 
 def algorithmic_bytes(N, E, D, header, elem=4):
@@ -146,24 +191,42 @@ class _Frontend:
 # ------------------------------------------------------------------------------------------------
 # rocprofv3 counter passes of this very benchmark, run as child processes BEFORE this process touches the GPU
 # ------------------------------------------------------------------------------------------------
-PMC_PASSES = {"fetch": ["FETCH_SIZE"], "write": ["WRITE_SIZE"], "l2": ["TCC_HIT_sum", "TCC_MISS_sum"]}
+PMC_PASSES = {"fetch": ["FETCH_SIZE"], "write": ["WRITE_SIZE"], "l2": ["TCC_HIT_sum", "TCC_MISS_sum"],
+              "mfma": ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]}
 
 
-def _read_counters(d):
+def case_key(workload, D, dtype="f32"):
+    return "%s_d%d%s" % (workload, D, "" if dtype == "f32" else "_" + dtype)
+
+
+def _read_counter_segments(d):
+    """Counters of one rocprofv3 pass, cut into one segment per benchmark case.  The child runs its cases one after the
+    other and every case begins with exactly one preprocess, whose first launch is the library's edge_to_row_kernel: that
+    dispatch marks the start of a segment.  -> [ {counter: {kernel: mean value per launch}} ] in case order."""
     import collections
     import csv
-    acc = collections.defaultdict(list)
+    rows = []
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         with open(f) as fh:
             for r in csv.DictReader(fh):
-                if "hcspmm::" in r.get("Kernel_Name", ""):
-                    acc[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in acc.items()}
+                rows.append((int(r["Dispatch_Id"]), r.get("Kernel_Name", ""), r["Counter_Name"], float(r["Counter_Value"])))
+    rows.sort(key=lambda r: r[0])
+    segs, marker_ids = [], set()
+    for did, name, counter, value in rows:
+        if "edge_to_row_kernel" in name:
+            if did not in marker_ids:
+                marker_ids.add(did)
+                segs.append(collections.defaultdict(lambda: collections.defaultdict(list)))
+        elif "hcspmm::" in name and segs:
+            segs[-1][counter][name.split("(")[0]].append(value)
+    return [{c: {k: sum(v) / len(v) for k, v in per.items()} for c, per in seg.items()} for seg in segs]
 
 
-def live_pmc(args, cache_dir, passes):
-    """-> dict with per-step counters of the headline launch, or {"error": ...}.  Each pass is its own run of
-    `rocprofv3 --pmc <set> --kernel-trace -- python3 bench.py --pmc-child ...` (the program directly after `--`)."""
+def live_pmc(args, cache_dir, cases, passes):
+    """-> {case key: {"fetch_bytes", "write_bytes", "traffic_bytes", "l2_hit_rate", "mfma_util_percent", ...}} plus
+    "_passes" (seconds per pass), or {"error": ...}.  Each pass is ONE run of
+    `rocprofv3 --pmc <set> --kernel-trace -- python3 bench.py --pmc-child --cases ...` (the program directly after `--`)
+    that executes every case in turn on the graphs this process has already generated (cache_dir)."""
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof):
         return {"error": "rocprofv3 not found"}
@@ -171,11 +234,15 @@ def live_pmc(args, cache_dir, passes):
     # nested profiler runs: the recorded figures are used instead
     if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
         return {"error": "already running under a profiler: live counter passes skipped"}
-    out = {"passes": {}, "counters": {}}
-    child = ["python3", os.path.join(ROOT, "bench.py"), "--pmc-child", "--graph-cache", cache_dir, "--workload", args.workload,
-             "--dim", str(args.dim), "--steps", "4", "--warmup", "2", "--rule", str(args.rule), "--dtype", args.dtype,
+    out = {"_passes": {}}
+    child = ["python3", os.path.join(ROOT, "bench.py"), "--pmc-child", "--graph-cache", cache_dir,
+             "--cases", ",".join("%s:%d" % (w, d) for w, d in cases), "--workload", args.workload, "--dim", str(args.dim),
+             "--steps", "4", "--warmup", "2", "--rule", str(args.rule), "--dtype", args.dtype,
              "--frontend", args.frontend, "--virtual-world", str(args.virtual_world)] + (["--no-plan"] if args.no_plan else [])
     env = dict(os.environ, TMPDIR="/tmp")
+    keys = [case_key(w, d, args.dtype if i == 0 else "f32") for i, (w, d) in enumerate(cases)]
+    per_case = {k: {"counters": {}} for k in keys}
+    budget = float(os.environ.get("HCSPMM_BENCH_PMC_TIMEOUT", "240"))
     for name in passes:
         d = os.path.join(cache_dir, "pmc_" + name)
         cmd = [rocprof, "--pmc"] + PMC_PASSES[name] + ["--kernel-trace", "--output-format", "csv", "-d", d, "--"] + child
@@ -183,7 +250,7 @@ def live_pmc(args, cache_dir, passes):
         try:
             p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, start_new_session=True)
             try:
-                log, _ = p.communicate(timeout=150)
+                log, _ = p.communicate(timeout=budget)
             except subprocess.TimeoutExpired:
                 os.killpg(p.pid, 9)
                 p.wait()
@@ -192,23 +259,33 @@ def live_pmc(args, cache_dir, passes):
                 return {"error": "rocprofv3 pass '%s' exited %d: %s" % (name, p.returncode, log.decode(errors="replace")[-300:])}
         except Exception as e:  # profiler trouble is reported, never fatal
             return {"error": "rocprofv3 pass '%s': %s" % (name, str(e)[:200])}
-        got = _read_counters(d)
-        if not got:
-            return {"error": "rocprofv3 pass '%s' produced no counters for hcspmm kernels" % name}
-        out["passes"][name] = round(time.perf_counter() - t0, 1)
-        for (k, c), v in got.items():
-            out["counters"].setdefault(c, {})[k] = v
-    c = out["counters"]
-    # MI355X_MICROARCH.md (HBM / rocprofv3): both counters are in KiB; on gfx950 FETCH_SIZE reports half of the bytes
-    # of wide (16 B / lane) reads -> doubled; WRITE_SIZE is exact for 16-byte stores.  Summed over the launches of a
-    # step (hybrid kernel + fix-up); tools/calibrate_fetch_size.py checks the factor on a copy of known size.
-    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-        out["fetch_bytes"] = 2.0 * 1024.0 * sum(c["FETCH_SIZE"].values())
-        out["write_bytes"] = 1024.0 * sum(c["WRITE_SIZE"].values())
-        out["traffic_bytes"] = out["fetch_bytes"] + out["write_bytes"]
-    if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
-        hit, miss = sum(c["TCC_HIT_sum"].values()), sum(c["TCC_MISS_sum"].values())
-        out["l2_hit_rate"] = hit / max(hit + miss, 1.0)
+        segs = _read_counter_segments(d)
+        if len(segs) != len(cases) or not all(segs):
+            return {"error": "rocprofv3 pass '%s': %d counter segments for %d cases" % (name, len(segs), len(cases))}
+        out["_passes"][name] = round(time.perf_counter() - t0, 1)
+        for k, seg in zip(keys, segs):
+            per_case[k]["counters"].update(seg)
+        shutil.rmtree(d, ignore_errors=True)
+    for k in keys:
+        c = per_case[k]["counters"]
+        e = {}
+        # MI355X_MICROARCH.md (HBM / rocprofv3): both counters are in KiB; on gfx950 FETCH_SIZE reports half of the bytes
+        # of wide (16 B / lane) reads -> doubled; WRITE_SIZE is exact for 16-byte stores.  Summed over the launches of a
+        # step (hybrid kernel + fix-up); tools/calibrate_fetch_size.py checks the factor on a copy of known size.
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            e["fetch_bytes"] = 2.0 * 1024.0 * sum(c["FETCH_SIZE"].values())
+            e["write_bytes"] = 1024.0 * sum(c["WRITE_SIZE"].values())
+            e["traffic_bytes"] = e["fetch_bytes"] + e["write_bytes"]
+        if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
+            hit, miss = sum(c["TCC_HIT_sum"].values()), sum(c["TCC_MISS_sum"].values())
+            e["l2_hit_rate"] = hit / max(hit + miss, 1.0)
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
+            # rocprofv3's MfmaUtil: MFMA-busy cycles summed over the SIMDs / (GPU-active cycles x SIMDs); GRBM_GUI_ACTIVE is
+            # summed over the 8 XCDs (MI355X_MICROARCH.md, DVFS note).  The hybrid kernel only (the fix-up has no MFMA).
+            hk = [k2 for k2 in c["GRBM_GUI_ACTIVE"] if "hybrid" in k2]
+            if hk and c["GRBM_GUI_ACTIVE"][hk[0]] > 0:
+                e["mfma_util_percent"] = 100.0 * c["SQ_VALU_MFMA_BUSY_CYCLES"].get(hk[0], 0.0) / (c["GRBM_GUI_ACTIVE"][hk[0]] / 8.0 * 1024.0)
+        out[k] = e
     return out
 
 
@@ -274,7 +351,7 @@ def cpu_baseline(rp, col, X_host, D, n_cols, budget_s=20.0):
 
 # ------------------------------------------------------------------------------------------------
 def run_case(fe, dev, workload, D, rp, col, n_local, world, rank, vworld, steps, warmup, dtype_name="f32", rule=0,
-             no_plan=False, n_gather_panels=0, dist=None):
+             no_plan=False, n_gather_panels=0, dist=None, prep_runs=2):
     """Preprocess + `steps` timed steps of one workload on this rank; returns the measurements (no printing)."""
     import torch
     from hcspmm.sharded import ShardedGraph, ShardedSpMM
@@ -287,7 +364,7 @@ def run_case(fe, dev, workload, D, rp, col, n_local, world, rank, vworld, steps,
     rp_d, col_d = torch.from_numpy(rp).to(dev), torch.from_numpy(col).to(dev)
     W = (n_local + 15) // 16
     prep = []
-    for _ in range(2):  # cold (first touch: pinned staging buffers, code objects, allocator growth), then warm
+    for _ in range(prep_runs):  # cold (first touch: pinned staging buffers, code objects, allocator growth), then warm
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         bp, e2c, e2r, ht, row_nzr, col_nzr = fe.preprocess(col_d, rp_d, n_local, E, W, rule, n_cols)
@@ -362,7 +439,7 @@ def run_case(fe, dev, workload, D, rp, col, n_local, world, rank, vworld, steps,
     flags = np.zeros(n_cols, dtype=bool)
     flags[col] = True
     return {"workload": workload, "D": D, "N": n_local, "E": E, "n_cols": n_cols, "elem": elem, "header": header,
-            "elapsed": elapsed, "steps": steps, "kernel_ms": kern_ms, "prep_cold_ms": prep[0], "prep_warm_ms": prep[1],
+            "elapsed": elapsed, "steps": steps, "kernel_ms": kern_ms, "prep_cold_ms": prep[0], "prep_warm_ms": prep[-1],
             "n_gather_panels": n_gather_panels, "cols_referenced": int(flags.sum()), "x_rows": n_cols,
             "hip_graph_ms_per_step": graph_ms}
 
@@ -410,12 +487,67 @@ def roofline_of(case, traffic=None, traffic_source=None):
     return r
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks as fresh child processes of this very command
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set; nothing here has touched a GPU -- counting devices does not initialise
+    one on this image), relay rank 0's JSON line, exit non-zero if any rank does."""
+    import torch
+    rehearsal = os.environ.get("HCSPMM_BENCH_REHEARSAL", "0") == "1"
+    dry = os.environ.get("HCSPMM_BENCH_DRYRUN", "0") == "1"
+    visible = torch.cuda.device_count()
+    if visible < n and not (rehearsal or dry):
+        print("bench.py: --gpus %d needs %d visible GPUs, found %d (HCSPMM_BENCH_REHEARSAL=1 runs every rank on GPU 0 over gloo "
+              "to rehearse the plumbing)" % (n, n, visible), file=sys.stderr)
+        return 3
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HCSPMM_BENCH_LAUNCHER="self")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad or all(c is not None for c in codes):
+                rc = bad[0] if bad else 0
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:  # a failed rank leaves the others waiting in a collective: stop exactly the processes started here
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+    reader.join(timeout=10)
+    out0 = b"".join(c for c in chunks if c)
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    if rc != 0:
+        print("bench.py: a rank exited with code %d" % rc, file=sys.stderr)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)  # SAG.profile's round count, GNN_model.py:251
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="reddit", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="reddit", choices=sorted(WORKLOADS) + sorted(STRONG_WORKLOADS))
     ap.add_argument("--dim", type=int, default=0)
     ap.add_argument("--frontend", default="ctypes", choices=["ctypes", "extension"],
                     help="Python front-end over the C ABI: the ctypes glue, or the torch extension HCSPMM (the reference's boundary)")
@@ -429,44 +561,85 @@ def main():
     ap.add_argument("--virtual-world", type=int, default=0,
                     help="one-GPU run of ONE rank's local product in a P-GPU job: the row block references columns of "
                          "all P blocks and X holds all P*n rows (already 'gathered'); no communication is timed (0 = the workload's own)")
+    ap.add_argument("--strong-scale", type=int, default=1, help=argparse.SUPPRESS)  # tests: shrink a strong-scaling graph by this factor
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--graph-cache", default="", help="directory holding (or receiving) the generated headline graph as rp.npy / col.npy")
+    ap.add_argument("--cases", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--graph-cache", default="", help="directory holding (or receiving) the generated graphs as <workload>_rp.npy / _col.npy")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        print("bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
-              % (args.gpus, args.gpus), file=sys.stderr)
-        sys.exit(2)
-    n_local, e_local, d_default, vw_default, desc = WORKLOADS[args.workload]
+    launcher = os.environ.get("HCSPMM_BENCH_LAUNCHER", "torch.distributed.run" if world > 1 else "none")
+    if os.environ.get("HCSPMM_BENCH_DRYRUN", "0") == "1" and world > 1:
+        # launcher self-test (tests/test_bench_cpu.py, no GPU): rendezvous over gloo, one collective, rank 0 prints a line
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t)
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"dryrun": True, "world_size": dist.get_world_size(), "sum_of_ranks_plus_one": t.item(),
+                              "backend": dist.get_backend(), "launcher": launcher, "argv": sys.argv[1:]}))
+        dist.destroy_process_group()
+        return
+    strong = args.workload in STRONG_WORKLOADS
+    if strong:
+        n_total, e_total, d_default, desc = STRONG_WORKLOADS[args.workload]
+        vw_default = 1
+    else:
+        n_local, e_local, d_default, vw_default, desc = WORKLOADS[args.workload]
     args.dim = args.dim or d_default
     if args.virtual_world <= 0:
         args.virtual_world = vw_default
     D = args.dim
     vworld = max(1, args.virtual_world) if world == 1 else 1
 
-    # ---- the headline graph (host, numpy): made before anything touches the GPU so that the counter passes share it
+    # ---- the graphs (host, numpy): made before anything touches the GPU so that the counter passes share them
     cache_dir = args.graph_cache
     own_cache = False
-    if cache_dir and os.path.exists(os.path.join(cache_dir, "col.npy")):
-        rp, col = np.load(os.path.join(cache_dir, "rp.npy")), np.load(os.path.join(cache_dir, "col.npy"))
-    else:
-        rp, col = make_local_block(args.workload, n_local, e_local, world * vworld, rank)
-        if cache_dir and world == 1:  # tools/profile_round.sh: the five passes of one workload share one generated graph
-            os.makedirs(cache_dir, exist_ok=True)
-            np.save(os.path.join(cache_dir, "rp.npy"), rp)
-            np.save(os.path.join(cache_dir, "col.npy"), col)
-    pmc = None
-    import torch  # (importing does not initialise the GPU; doing it first pages the library in for the child processes too)
-    if world == 1 and not args.pmc_child and not args.no_pmc:
+    do_sweep = world == 1 and not args.no_sweep and not strong and not args.pmc_child
+    do_pmc = world == 1 and not args.pmc_child and not args.no_pmc and not strong
+    if do_pmc and not cache_dir:
         cache_dir = tempfile.mkdtemp(prefix="hcspmm_bench_")
         own_cache = True
-        np.save(os.path.join(cache_dir, "rp.npy"), rp)
-        np.save(os.path.join(cache_dir, "col.npy"), col)
-        passes = [p for p in os.environ.get("HCSPMM_BENCH_PMC", "fetch,write,l2").split(",") if p in PMC_PASSES]
-        pmc = live_pmc(args, cache_dir, passes)
+    graphs_host = {}
+
+    def graph_of(wl):
+        """(rp, col) of workload `wl` as one GPU sees it: from the cache directory when it is there, else generated (and cached)."""
+        if wl not in graphs_host:
+            f_rp, f_col = (os.path.join(cache_dir, "%s_%s.npy" % (wl, n)) for n in ("rp", "col")) if cache_dir else (None, None)
+            if cache_dir and os.path.exists(f_col):
+                graphs_host[wl] = (np.load(f_rp), np.load(f_col))
+            else:
+                nl, el, _, vw, _ = WORKLOADS[wl]
+                w = world * vworld if wl == args.workload else vw
+                graphs_host[wl] = make_local_block(wl, nl, el, w, rank)
+                if cache_dir and world == 1:
+                    os.makedirs(cache_dir, exist_ok=True)
+                    np.save(f_rp, graphs_host[wl][0])
+                    np.save(f_col, graphs_host[wl][1])
+        return graphs_host[wl]
+
+    if strong:
+        rp, col, n_local, n_total = make_strong_block(args.workload, world, rank, scale=max(1, args.strong_scale))
+        e_local = len(col)
+    else:
+        rp, col = graph_of(args.workload)
+    sweep_plan = [(w, d) for w, d in SWEEP_PLAN if not (w == args.workload and d == D)] if do_sweep else []
+    cases = [(args.workload, D)] + sweep_plan
+    if args.pmc_child and args.cases:
+        cases = [(c.split(":")[0], int(c.split(":")[1])) for c in args.cases.split(",")]
+    pmc = None
+    import torch  # (importing does not initialise the GPU; doing it first pages the library in for the child processes too)
+    if do_pmc:
+        for w, _ in cases:
+            graph_of(w)
+        passes = [p for p in os.environ.get("HCSPMM_BENCH_PMC", "fetch,write,l2,mfma").split(",") if p in PMC_PASSES]
+        pmc = live_pmc(args, cache_dir, cases, passes)
 
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the hot path has no CPU fallback", file=sys.stderr)
@@ -474,6 +647,10 @@ def main():
     # HCSPMM_BENCH_REHEARSAL=1: every rank on GPU 0 with gloo collectives -- lets the N > 1 plumbing run
     # on a one-GPU box (numbers from it are meaningless and are labelled as such)
     rehearsal = os.environ.get("HCSPMM_BENCH_REHEARSAL", "0") == "1"
+    visible = torch.cuda.device_count()
+    if world > 1 and not rehearsal and visible < world:
+        print("bench.py: %d ranks but only %d visible GPUs" % (world, visible), file=sys.stderr)
+        sys.exit(3)
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -488,10 +665,18 @@ def main():
 
     fe = _Frontend(args.frontend)
     n_gather_panels = int(os.environ.get("HCSPMM_GATHER_PANELS", "0"))
+    if args.pmc_child:
+        # one process, every case in turn, ONE preprocess each (its edge_to_row_kernel launch marks the case in the counter output)
+        for i, (w, d) in enumerate(cases):
+            nl, _, _, vw, _ = WORKLOADS[w]
+            rp_c, col_c = graph_of(w)
+            head = i == 0 and w == args.workload
+            run_case(fe, dev, w, d, rp_c, col_c, nl, 1, 0, vworld if head else vw, args.steps, args.warmup,
+                     args.dtype if head else "f32", args.rule if head else 0, args.no_plan if head else False, 0, None, prep_runs=1)
+            torch.cuda.empty_cache()
+        return
     case = run_case(fe, dev, args.workload, D, rp, col, n_local, world, rank, vworld, args.steps, args.warmup, args.dtype,
                     args.rule, args.no_plan, n_gather_panels, dist)
-    if args.pmc_child:
-        return
     elapsed, E, header = case["elapsed"], case["E"], case["header"]
 
     red_dev = torch.device("cpu") if rehearsal else dev
@@ -505,13 +690,13 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        key = "%s_d%d%s" % (args.workload, D, "" if args.dtype == "f32" else "_" + args.dtype)
+        key = case_key(args.workload, D, args.dtype)
         traffic, source, extra = None, None, {}
-        if pmc and "traffic_bytes" in pmc:
-            traffic = pmc["traffic_bytes"]
+        if pmc and key in pmc and "traffic_bytes" in pmc[key]:
+            traffic = pmc[key]["traffic_bytes"]
             source = ("this run: rocprofv3 --pmc child passes of bench.py on the same graph before the timed region "
-                      "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB); seconds per pass %s" % json.dumps(pmc["passes"]))
-            extra = {"fetch_bytes": pmc.get("fetch_bytes"), "write_bytes": pmc.get("write_bytes"), "l2_hit_rate": pmc.get("l2_hit_rate")}
+                      "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB); seconds per pass (all cases) %s" % json.dumps(pmc["_passes"]))
+            extra = {k: pmc[key].get(k) for k in ("fetch_bytes", "write_bytes", "l2_hit_rate", "mfma_util_percent")}
         elif world == 1 and args.rule == 0 and not args.no_plan:
             rec = recorded_profile(key)
             if rec and not rec.get("stale"):
@@ -522,23 +707,32 @@ def main():
         roof.update({k: v for k, v in extra.items() if v is not None})
         if pmc and "error" in pmc:
             roof["pmc_error"] = pmc["error"]
+        if strong:
+            workload_txt = ("%s: %s; %d nodes / %d stored entries in all, %d / %d on rank 0, dim %d"
+                            % (args.workload, desc, n_total, int(total_edges), n_local, E, D))
+        else:
+            workload_txt = ("%s: %s; %d nodes / %d stored entries per GPU, dim %d%s"
+                            % (args.workload, desc, n_local, E, D,
+                               "" if vworld == 1 else "; ONE rank of a virtual %d-GPU job (X: %d rows resident)" % (vworld, n_local * vworld)))
         out = {
             "metric": "GNN-aggregation SpMM edges*dim/s (A*X, %s)" % ("fp32" if args.dtype == "f32" else args.dtype + " features, fp32 accumulation"),
             "value": total_edges * D / (elapsed / args.steps),
             "unit": "edge*dim/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo -- not a measurement)" if rehearsal else ""),
-            "config": {"workload": "%s: %s; %d nodes / %d stored entries per GPU, dim %d%s"
-                                   % (args.workload, desc, n_local, E, D,
-                                      "" if vworld == 1 else "; ONE rank of a virtual %d-GPU job (X: %d rows resident)" % (vworld, n_local * vworld)),
+            "config": {"workload": workload_txt,
                        "nodes_per_gpu": n_local, "entries_per_gpu": E, "dim": D,
                        "parallelism": "row-block shard x%d + all-gather(X) in %d column panel(s), panel-major persistent buffers"
                                       % (world, case["n_gather_panels"] if world > 1 else 1),
                        "frontend": args.frontend, "plan": (not args.no_plan), "rule": args.rule, "sparse_tasks": header.n_tasks,
                        "dense_windows": header.n_dense, "split_rows": header.n_split_rows,
+                       "column_slices": getattr(header, "n_slices", 0), "slice_threshold": getattr(header, "slice_threshold", 0),
                        "preprocess_ms": case["prep_warm_ms"], "preprocess_ms_cold": case["prep_cold_ms"],
                        "kernel_src_sha": kernel_src_sha()},
+            "distributed": {"world_size": dist.get_world_size() if world > 1 else 1,
+                            "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if world > 1 else None,
+                            "visible_gpus": visible, "launcher": launcher},
             "roofline": roof,
         }
         if world > 1:
@@ -554,11 +748,11 @@ def main():
                                     "note": "communication-bound by construction (DESIGN.md section 6): the gathered bytes grow with the "
                                             "world size while the local product does not; only the last panel's product is exposed"}
         torch.cuda.empty_cache()
-        if world == 1 and not args.no_sweep:
-            out["sweep"] = sweep(fe, dev, args, rp, col)
-        if world == 1 and not args.no_cpu_baseline:
-            Xh = torch.randn(n_local * vworld, D, generator=torch.Generator().manual_seed(1234)).numpy()
-            out["cpu_baseline"] = cpu_baseline(rp, col, Xh, D, n_local * vworld)
+        if sweep_plan:
+            out["sweep"] = sweep(fe, dev, args, sweep_plan, graph_of, pmc)
+        if world == 1 and not args.no_cpu_baseline and not strong:
+            Xh = torch.randn(case["x_rows"], D, generator=torch.Generator().manual_seed(1234)).numpy()
+            out["cpu_baseline"] = cpu_baseline(rp, col, Xh, D, case["x_rows"])
         print(json.dumps(out))
     if own_cache:
         shutil.rmtree(cache_dir, ignore_errors=True)
@@ -567,43 +761,47 @@ def main():
         dist.destroy_process_group()
 
 
-def sweep(fe, dev, args, rp_head, col_head):
-    """The other BASELINE points, timed in this process after the headline (fewer steps each)."""
+def sweep(fe, dev, args, plan, graph_of, pmc):
+    """The other BASELINE points, timed in this process after the headline (fewer steps each); traffic / L2 hit rate /
+    MFMA utilisation of each from this run's own counter passes (`pmc`), the recorded table only when those failed."""
     import torch
     entries = []
     steps, warmup = max(10, min(args.steps, 50)), 5
-    plan = [("reddit", 32), ("reddit", 256), ("cora", 32), ("products_share", 256), ("c5_share", 128)]
     for wl, D in plan:
-        if wl == args.workload and D == args.dim:
-            continue
         n_local, e_local, _, vw, desc = WORKLOADS[wl]
         t0 = time.perf_counter()
         try:
-            if wl == args.workload:
-                rp, col = rp_head, col_head
-            else:
-                rp, col = make_local_block(wl, n_local, e_local, vw, 0)
+            rp, col = graph_of(wl)
             gen_s = time.perf_counter() - t0
             case = run_case(fe, dev, wl, D, rp, col, n_local, 1, 0, vw, steps, warmup, "f32", 0)
-            rec = recorded_profile("%s_d%d" % (wl, D))
-            traffic = rec.get("traffic_bytes") if rec else None
-            src = None
-            if traffic:
-                src = "recorded: %s%s" % (rec.get("source"), " (STALE: kernel sources changed since)" if rec.get("stale") else "")
+            key = case_key(wl, D)
+            live = pmc.get(key) if pmc and "error" not in pmc else None
+            traffic, src, rec = None, None, None
+            if live and live.get("traffic_bytes"):
+                traffic = live["traffic_bytes"]
+                src = "this run: rocprofv3 --pmc child passes of bench.py on the same graph before the timed region"
+            else:
+                rec = recorded_profile(key)
+                traffic = rec.get("traffic_bytes") if rec else None
+                if traffic:
+                    src = "recorded: %s%s%s" % (rec.get("source"), " (STALE: kernel sources changed since)" if rec.get("stale") else "",
+                                                 "; live counter passes failed: " + pmc["error"] if pmc and "error" in pmc else "")
             roof = roofline_of(case, traffic, src)
             h = case["header"]
             e = {"workload": wl, "dim": D, "nodes": n_local, "entries": case["E"], "x_rows_resident": case["x_rows"],
                  "steps": steps, "ms_per_step": case["elapsed"] / steps * 1e3, "kernel_ms": case["kernel_ms"],
                  "value": case["E"] * D / (case["elapsed"] / steps), "unit": "edge*dim/s",
                  "sparse_tasks": h.n_tasks, "dense_windows": h.n_dense, "nnz_dense": h.nnz_dense, "split_rows": h.n_split_rows,
+                 "column_slices": getattr(h, "n_slices", 0),
                  "preprocess_ms": case["prep_warm_ms"], "graph_gen_s": round(gen_s, 1), "roofline": roof, "desc": desc}
             if case.get("hip_graph_ms_per_step") is not None:
                 e["hip_graph_ms_per_step"] = case["hip_graph_ms_per_step"]
                 e["hip_graph_note"] = "the same step captured in a HIP graph and replayed: launch-bound workload, the Python call costs more than the kernel"
+            for k in ("l2_hit_rate", "mfma_util_percent", "fetch_bytes", "write_bytes"):
+                v = (live or {}).get(k) if live else (rec or {}).get(k)
+                if v is not None:
+                    e[k] = v
             if rec:
-                for k in ("l2_hit_rate", "mfma_util_percent", "mfma_flops_per_launch"):
-                    if rec.get(k) is not None:
-                        e[k] = rec[k]
                 e["profile_source"] = rec.get("source")
                 e["profile_stale"] = rec.get("stale")
             entries.append(e)

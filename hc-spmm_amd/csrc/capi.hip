@@ -310,7 +310,8 @@ extern "C" int hcspmm_forward(const float* X, float* Z, const int32_t* rowptr, c
 // asks for it (hcspmm_plan_params.fuse_in_launch; HCSPMM_FUSED_SINGLE_LAUNCH=1 / 0 forces it on / off for every
 // plan), has dense windows and the shape is in range: fp32, D a multiple of 16 from 32 up, H = 16 or 32, W fits the
 // LDS staging area, 16-byte aligned rows.  Not the default: on MI355X it is the slower form (profiles/r02/ab_fused.log).
-static bool fused_single_launch_ok(const hcspmm_plan_header* ph, const void* X, const void* out2, int D, int H) {
+static bool fused_single_launch_ok(const hcspmm_plan_header* ph, const void* X, const void* out2, int D, int H,
+                                   const void* workspace = nullptr) {
   static const int forced = [] {
     const char* e = getenv("HCSPMM_FUSED_SINGLE_LAUNCH");
     return !e ? -1 : (e[0] == '0' ? 0 : 1);
@@ -318,7 +319,9 @@ static bool fused_single_launch_ok(const hcspmm_plan_header* ph, const void* X, 
   if (!ph || ph->n_dense <= 0) return false;
   if (forced == 0 || (forced < 0 && !(ph->flags & HCSPMM_PLAN_FUSE_IN_LAUNCH))) return false;
   if (D % 16 != 0 || D < 32 || H % 16 != 0 || H > 32 || H <= 0) return false;
-  if (!aligned(X, 16) || !aligned(out2, 16)) return false;
+  // the in-launch kernel is the 16-byte-per-lane build: a caller's workspace that is only 4- or 8-byte aligned takes the
+  // two-launch form (which serves every alignment) instead of failing
+  if (!aligned(X, 16) || !aligned(out2, 16) || (workspace && !aligned(workspace, 16))) return false;
   const int dv = D >= 64 ? 4 : 2;
   const int rows = (D + 16 * dv - 1) / (16 * dv) * 16 * dv;
   return (size_t)rows * (size_t)(H + 4) * sizeof(float) <= 64 * 1024;
@@ -336,7 +339,7 @@ extern "C" int hcspmm_forward_fused(const float* X, float* out, float* out2, con
                                     size_t workspace_bytes, void* stream_v) {
   if (!out || !out2 || !weights || H <= 0) return HCSPMM_EINVAL;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
-  if (plan_d && ph && fused_single_launch_ok(ph, X, out2, D, H)) {
+  if (plan_d && ph && fused_single_launch_ok(ph, X, out2, D, H, hcspmm_workspace_bytes(ph, D) ? workspace : nullptr)) {
     const FusedOperands f{weights, (long long)ldr, (long long)ldc, out, H};
     const int rc = forward_impl(X, N, D, out2, D, HCSPMM_DTYPE_F32, rowptr, col, blockPartition, edgeToColumn, edgeToRow,
                                 hybrid_type, plan_d, ph, N, E, D, workspace, workspace_bytes, stream_v, &f);

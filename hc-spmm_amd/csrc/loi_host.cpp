@@ -16,6 +16,7 @@
 #endif
 
 #include "hcspmm.h"
+#include "host_util.h"
 
 namespace {
 int loi_reorder_impl(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, int variant, int32_t* perm_out,
@@ -114,6 +115,7 @@ int loi_reorder_impl(const int32_t* rowptr, const int32_t* col, int64_t N, int64
                      int32_t* group_sizes_out, int64_t* n_groups_out) {
   if (N < 0 || E < 0 || !rowptr || (N > 0 && !perm_out) || (E > 0 && !col)) return HCSPMM_EINVAL;
   if (N > INT32_MAX - 16 || E > INT32_MAX) return HCSPMM_ERANGE;
+  if (!hcspmm::csr_row_pointers_ok(rowptr, N, E)) return HCSPMM_EINVAL;
   for (int64_t e = 0; e < E; ++e)
     if (col[e] < 0 || col[e] >= N) return HCSPMM_EINVAL;
 
@@ -272,6 +274,7 @@ int loi_reorder_windowed(const int32_t* rowptr, const int32_t* col, int64_t N, i
   if (N > INT32_MAX - 16 || E > INT32_MAX) return HCSPMM_ERANGE;
   constexpr int64_t kWindow = 300, kTail = 50;
   if (N < kTail) return HCSPMM_EINVAL;
+  if (!hcspmm::csr_row_pointers_ok(rowptr, N, E)) return HCSPMM_EINVAL;  // (the per-row loop below then stays inside col[0, E))
   for (int64_t r = 0; r < N; ++r) {
     if (rowptr[r + 1] <= rowptr[r]) return HCSPMM_EINVAL;  // an empty row: outside the reference's defined domain
     for (int32_t e = rowptr[r]; e < rowptr[r + 1]; ++e) {
@@ -403,6 +406,9 @@ extern "C" int hcspmm_apply_permutation(const int32_t* rowptr, const int32_t* co
                                         const int32_t* perm, int32_t* rowptr_out, int32_t* col_out) {
   if (N < 0 || E < 0 || !rowptr || !rowptr_out || (N > 0 && !perm) || (E > 0 && (!col || !col_out)))
     return HCSPMM_EINVAL;
+  if (!hcspmm::csr_row_pointers_ok(rowptr, N, E)) return HCSPMM_EINVAL;
+  for (int64_t e = 0; e < E; ++e)
+    if (col[e] < 0 || col[e] >= N) return HCSPMM_EINVAL;
   std::vector<int32_t> inv((size_t)N, -1);
   for (int64_t i = 0; i < N; ++i) {
     const int32_t old = perm[i];

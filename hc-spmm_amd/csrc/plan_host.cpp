@@ -617,7 +617,8 @@ extern "C" int hcspmm_plan_check(const hcspmm_plan_header* h, int64_t N, int64_t
   if (!h) return HCSPMM_EINVAL;
   if (h->magic != HCSPMM_PLAN_MAGIC || h->version != HCSPMM_PLAN_VERSION) return HCSPMM_EPLAN;
   if (h->num_nodes != N || h->num_edges != E) return HCSPMM_EPLAN;
-  if (h->num_windows != (N + HCSPMM_BLK_H - 1) / HCSPMM_BLK_H || h->num_columns <= 0) return HCSPMM_EPLAN;
+  if (h->num_windows != (N + HCSPMM_BLK_H - 1) / HCSPMM_BLK_H) return HCSPMM_EPLAN;
+  if (h->num_columns < 0 || (h->num_columns == 0 && N > 0)) return HCSPMM_EPLAN;  // (the plan of an empty graph gathers from nothing)
   if (h->n_tasks < 0 || h->n_dense < 0 || h->n_split_rows < 0 || h->n_partials < 0) return HCSPMM_EPLAN;
   if (h->n_tiny < 0 || h->n_tiny > h->n_tasks) return HCSPMM_EPLAN;
   if (h->n_dense_compact < 0 || h->n_dense_compact2 < 0 ||

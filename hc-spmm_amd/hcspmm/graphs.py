@@ -136,8 +136,32 @@ def planted_dense_graph_fast(num_nodes, seed=0, dense_fraction=0.7, k_cols=16, f
     return _to_csr(rows, cols, N)
 
 
+_CDF_CACHE = {}
+
+
 def _capped_powerlaw_cdf(n, cap_prob, exponent=2.1):
-    """CDF of endpoint weights w_i ~ (i+1)^(-1/(exponent-1)) with every probability capped at cap_prob."""
+    """CDF of endpoint weights w_i ~ (i+1)^(-1/(exponent-1)) with every probability capped at cap_prob.  (The last result
+    is kept: the chunks of one strong-scaling graph -- bench.py make_strong_block -- ask for the same 16 M-entry table.)"""
+    key = (int(n), float(cap_prob), float(exponent))
+    if key in _CDF_CACHE:
+        return _CDF_CACHE[key]
+    c = _capped_powerlaw_cdf_uncached(n, cap_prob, exponent)
+    if len(_CDF_CACHE) >= 4:
+        _CDF_CACHE.clear()
+    _CDF_CACHE[key] = c
+    return c
+
+
+def _column_relabelling(n_cols, seed):
+    key = ("perm", int(n_cols), int(seed))
+    if key not in _CDF_CACHE:
+        if len(_CDF_CACHE) >= 4:
+            _CDF_CACHE.clear()
+        _CDF_CACHE[key] = np.random.default_rng(seed).permutation(n_cols)
+    return _CDF_CACHE[key]
+
+
+def _capped_powerlaw_cdf_uncached(n, cap_prob, exponent=2.1):
     alpha = 1.0 / (exponent - 1.0)
     w = (np.arange(n, dtype=np.float64) + 1.0) ** (-alpha)
     w /= w.sum()
@@ -163,7 +187,7 @@ def powerlaw_block(n_rows, n_cols, n_entries, seed=0, rank=0, rows=None):
     rcdf = _capped_powerlaw_cdf(n_draw_rows, cap)
     ccdf = _capped_powerlaw_cdf(n_cols, cap)
     rperm = rng.permutation(n_draw_rows)
-    cperm = np.random.default_rng(seed).permutation(n_cols)  # same column relabelling on every rank
+    cperm = _column_relabelling(n_cols, seed)  # same column relabelling on every rank
     draw = int(n_entries * 1.12)
     r = rperm[np.searchsorted(rcdf, rng.random(draw))].astype(np.int64)
     if rows is not None:

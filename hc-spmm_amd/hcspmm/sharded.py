@@ -98,7 +98,10 @@ class ShardedSpMM:
     allocates and copies nothing.
     """
 
-    def __init__(self, graph, local_spmm_into, group=None, n_panels=1, workspace_bytes=None):
+    def __init__(self, graph, local_spmm_into, group=None, n_panels=1, workspace_bytes=None, always_gather=False):
+        """always_gather: take the collective path even in a one-rank group (a one-GPU box can then run the gather /
+        product ordering through real RCCL; a one-rank job otherwise multiplies X_pm in place)."""
+        self.always_gather = bool(always_gather)
         self.g = graph
         self.local_spmm_into = local_spmm_into
         self.n_panels = max(1, int(n_panels))
@@ -112,17 +115,25 @@ class ShardedSpMM:
         if D % self.n_panels != 0:
             raise ValueError("embedding_dim %d is not a multiple of n_panels %d" % (D, self.n_panels))
         self.D, self.w = int(D), int(D) // self.n_panels
-        self.dtype, self.device = dtype, torch.device(device)
+        self.dtype, self.device = dtype, self._canonical(device)
         kw = dict(dtype=dtype, device=self.device)
         self.X_pm = torch.zeros((self.n_panels, g.pad_rows, self.w), **kw)  # padding rows stay zero
         self.Z_pm = torch.empty((self.n_panels, g.n_local, self.w), **kw)
         # world 1: the product reads X_pm itself
         self.gathered = [torch.empty((g.world_size * g.pad_rows, self.w), **kw) for _ in range(self.n_panels)] \
-            if g.world_size > 1 else None
+            if (g.world_size > 1 or self.always_gather) else None
         nbytes = int(self._workspace_bytes(self.w)) if self._workspace_bytes is not None else 0
         self.workspace = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=self.device) if nbytes else None
         self._host_stage = None
         return self
+
+    @staticmethod
+    def _canonical(device):
+        """torch.device("cuda") and torch.device("cuda:0") name the same GPU: compare with the index filled in."""
+        d = torch.device(device)
+        if d.type == "cuda" and d.index is None:
+            d = torch.device("cuda", torch.cuda.current_device())
+        return d
 
     def features(self):
         """Panel-major view [n_panels, n_local, w] of this rank's features, to be filled in place."""
@@ -151,7 +162,7 @@ class ShardedSpMM:
 
     def step(self):
         g = self.g
-        if g.world_size == 1:
+        if g.world_size == 1 and not self.always_gather:
             for p in range(self.n_panels):
                 self.local_spmm_into(self.X_pm[p], self.Z_pm[p], self.workspace)
             return self.Z_pm
@@ -163,13 +174,14 @@ class ShardedSpMM:
         return self.Z_pm
 
     def forward(self, X_local):
-        """Row-major convenience form: [n_local, D] -> [n_local, D] (a new tensor when n_panels > 1)."""
-        if self.D is None or self.D != X_local.shape[1] or self.dtype != X_local.dtype or self.device != X_local.device:
+        """Row-major convenience form: [n_local, D] -> a NEW [n_local, D] tensor (step() is the aliasing API: it returns the
+        persistent Z_pm, which the next step overwrites)."""
+        if self.D is None or self.D != X_local.shape[1] or self.dtype != X_local.dtype or self.device != self._canonical(X_local.device):
             self.bind(X_local.shape[1], X_local.dtype, X_local.device)
         self.load_features(X_local)
         Z_pm = self.step()
         if self.n_panels == 1:
-            return Z_pm[0]
+            return Z_pm[0].clone()
         return Z_pm.permute(1, 0, 2).reshape(self.g.n_local, self.D)
 
     __call__ = forward

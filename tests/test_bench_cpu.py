@@ -65,3 +65,86 @@ def test_every_workload_has_a_generator_entry():
         assert n > 0 and d > 0 and vw >= 1 and desc
     assert bench.WORKLOADS["reddit"][:3] == (233000, 11600000, 128)   # BASELINE config 3: the headline
     assert bench.WORKLOADS["c5_share"][:4] == (2000000, 32000000, 128, 8)  # BASELINE config 5, one GPU's share of 16 M / 256 M
+
+
+def _run_bench(argv, env=None, timeout=180):
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    e.update(env or {})
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          text=True, timeout=timeout)
+
+
+def test_plain_spelling_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it spawns the two ranks itself and relays rank 0's single line
+    (HCSPMM_BENCH_DRYRUN=1: the ranks rendezvous over gloo and stop before anything needs a GPU)."""
+    r = _run_bench(["--gpus", "2", "--steps", "3"], {"HCSPMM_BENCH_DRYRUN": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["world_size"] == 2 and out["sum_of_ranks_plus_one"] == 3.0 and out["launcher"] == "self" and out["backend"] == "gloo"
+
+
+def test_more_ranks_than_gpus_is_an_error_that_names_the_count():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs fewer than 2 visible GPUs")
+    r = _run_bench(["--gpus", "2", "--steps", "3"])
+    assert r.returncode == 3 and r.stdout == ""
+    assert "needs 2 visible GPUs, found %d" % torch.cuda.device_count() in r.stderr
+
+
+def test_a_failing_rank_fails_the_job():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("on a GPU box the rehearsal succeeds (tests/test_sharded_cpu.py runs it there)")
+    r = _run_bench(["--gpus", "2", "--steps", "2", "--workload", "cora"], {"HCSPMM_BENCH_REHEARSAL": "1"})
+    assert r.returncode != 0 and "no GPU visible" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_strong_scaling_blocks_are_the_partition_of_one_graph():
+    """--workload products / powerlaw16m / c5: every world size sees the same graph, and a rank's block is the block
+    hcspmm.sharded.partition_rows (nnz-balanced, window-aligned) cuts for it."""
+    import numpy as np
+    from hcspmm.sharded import partition_rows
+    for wl in ("products", "c5"):
+        full_rp, full_col, n1, n_total = bench.make_strong_block(wl, 1, 0, scale=64)
+        assert n1 == n_total == len(full_rp) - 1 and n_total % (16 * bench.STRONG_CHUNKS) == 0
+        for world in (2, 8):
+            blocks = [bench.make_strong_block(wl, world, r, scale=64) for r in range(world)]
+            ranges = [(r * n_total // world, (r + 1) * n_total // world) for r in range(world)]
+            # chunks have equal heights and (to a fraction of a percent) equal entry counts: the nnz-balanced cuts of
+            # partition_rows fall on the chunk boundaries, give or take a row window or two
+            for (a0, a1), (b0, b1) in zip(partition_rows(full_rp, world), ranges):
+                assert abs(a0 - b0) <= max(32, n_total // world // 200) and abs(a1 - b1) <= max(32, n_total // world // 200)
+            for r, (rp, col, n_local, nt) in enumerate(blocks):
+                r0, r1 = ranges[r]
+                assert nt == n_total and n_local == r1 - r0
+                assert np.array_equal(rp.astype(np.int64), full_rp[r0:r1 + 1].astype(np.int64) - int(full_rp[r0]))
+                assert np.array_equal(col, full_col[full_rp[r0]:full_rp[r1]])
+    with pytest.raises(SystemExit):
+        bench.make_strong_block("products", 3, 0, scale=64)
+
+
+def test_counter_segments_follow_the_preprocess_marker(tmp_path):
+    """One rocprofv3 pass covers every case: the counter rows are cut at each case's edge_to_row_kernel dispatch."""
+    d = tmp_path / "pmc_fetch" / "host"
+    d.mkdir(parents=True)
+    hdr = "Correlation_Id,Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value\n"
+    rows = []
+
+    def add(did, name, val):
+        rows.append('%d,%d,"%s","FETCH_SIZE",%f\n' % (did, did, name, val))
+    e2r, hyb, fix = "(anonymous namespace)::edge_to_row_kernel(int const*, int, long long, int*)", \
+        "void hcspmm::hybrid_plan_kernel<hcspmm::F32, 8, 4, 8, 5, false>(hcspmm::PlanArgs)", "void hcspmm::fixup_kernel<hcspmm::F32, 4>(hcspmm::PlanArgs)"
+    add(1, e2r, 5.0); add(2, "copyBuffer", 1.0); add(3, hyb, 100.0); add(4, fix, 10.0); add(5, hyb, 300.0); add(6, fix, 30.0)
+    add(7, e2r, 5.0); add(8, hyb, 7.0)
+    (d / "1_counter_collection.csv").write_text(hdr + "".join(reversed(rows)))  # order in the file does not matter
+    segs = bench._read_counter_segments(str(tmp_path / "pmc_fetch"))
+    assert len(segs) == 2
+    assert segs[0]["FETCH_SIZE"] == {"void hcspmm::hybrid_plan_kernel<hcspmm::F32, 8, 4, 8, 5, false>": 200.0, "void hcspmm::fixup_kernel<hcspmm::F32, 4>": 20.0}
+    assert segs[1]["FETCH_SIZE"] == {"void hcspmm::hybrid_plan_kernel<hcspmm::F32, 8, 4, 8, 5, false>": 7.0}

@@ -200,6 +200,50 @@ def _nccl_worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
+def _nccl_single_rank_worker(rank, world, port, out_dir):
+    """A ONE-rank RCCL group on GPU 0 with the collective path forced (always_gather): what a one-GPU box can run of the
+    production path -- RCCL initialisation, all_gather_into_tensor(async_op=True) on RCCL's stream, work.wait() ordering
+    the product on the current stream behind it, persistent buffers -- against the plain single-GPU product."""
+    for p in (ROOT, os.path.join(ROOT, "hc-spmm_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import hcspmm
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        rp, col = graphs.powerlaw_graph(20011, 400000, seed=21, max_degree_frac=0.2)
+        N, D = len(rp) - 1, 128
+        g = ShardedGraph(rp, col, partition_rows(rp, 1), 0)
+        rp_d, col_d = torch.from_numpy(g.row_pointers).to(dev), torch.from_numpy(g.column_index).to(dev)
+        outs = hcspmm.preprocess(col_d, rp_d, g.n_local, len(g.column_index), (g.n_local + 15) // 16, num_columns=g.num_columns)
+        op = ShardedSpMM(g, lambda Xf, Zv, ws: hcspmm.forward_into(Xf, Zv, rp_d, col_d, *outs, workspace=ws), n_panels=4,
+                         workspace_bytes=lambda w: hcspmm.workspace_bytes(outs[4], w), always_gather=True)
+        ok = True
+        for it in range(4):  # new features every step: a product that ran ahead of its gather would read the previous ones
+            X = torch.randn(N, D, device=dev, generator=torch.Generator(device=dev).manual_seed(it))
+            Z = op(X)
+            ok = ok and op.gathered is not None and torch.equal(Z, hcspmm.forward(X, rp_d, col_d, *outs)[0])
+        Z1 = op(X)
+        Z2 = op(2 * X)
+        ok = ok and Z1.data_ptr() != Z2.data_ptr() and torch.equal(Z1, hcspmm.forward(X, rp_d, col_d, *outs)[0])  # forward() does not alias
+        torch.cuda.synchronize()
+        np.save(os.path.join(out_dir, "nccl1_ok.npy"), np.array([int(ok), dist.get_world_size()]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_spmm_through_a_single_rank_rccl_group(tmp_path):
+    port = _free_port()
+    mp.spawn(_nccl_single_rank_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    ok, world = np.load(tmp_path / "nccl1_ok.npy")
+    assert ok == 1 and world == 1
+
+
 @pytest.mark.gpu
 def test_sharded_spmm_nccl_one_rank_per_gpu(tmp_path):
     """Runs only where more than one GPU is visible (the builder's box has one; the driver's scaling node has 8):

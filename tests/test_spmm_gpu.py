@@ -121,6 +121,7 @@ CASES = [
     ("planted_dense", lambda: graphs.planted_dense_graph(1500, seed=4), True),
     ("one_node", lambda: (np.array([0, 1], np.int32), np.array([0], np.int32)), True),
     ("no_edges", lambda: (np.zeros(50, np.int32), np.zeros(0, np.int32)), True),
+    ("no_nodes", lambda: (np.zeros(1, np.int32), np.zeros(0, np.int32)), True),  # N = 0: both front-ends return an empty Z
 ]
 
 

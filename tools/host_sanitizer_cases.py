@@ -33,5 +33,17 @@ for trial in range(40):
         rp2=np.zeros(N+1,np.int32); col2=np.zeros(E,np.int32)
         L.hcspmm_loi_reorder_variant(P(rp),P(col),i64(N),i64(E),0,P(perm),P(gs),ctypes.byref(ng))
         rc=L.hcspmm_apply_permutation(P(rp),P(col),i64(N),i64(E),P(perm),P(rp2),P(col2)); assert rc==0
+    if N >= 50 and E > 0:  # malformed row pointers must be refused before any column is read (all LOI variants, plan, preprocess)
+        for bad0, badN in ((1, rp[-1]), (0, rp[-1] + 7), (0, max(rp[-1] - 1, 0)), (-3, rp[-1])):
+            rb = rp.copy(); rb[0] = bad0; rb[-1] = badN
+            for variant in (0,1,2,3):
+                rc=L.hcspmm_loi_reorder_variant(P(rb),P(col),i64(N),i64(E),variant,P(perm),P(gs),ctypes.byref(ng)); assert rc==-1,(variant,rc)
+            rc=L.hcspmm_plan_build(P(rb),P(col),i64(N),i64(E),i64(N),P(bp),P(e2c),P(ht),None,P(plan),i64(len(plan))); assert rc==-1,rc
+    # XCD-affine column slices forced on (any size), 8 and 24 slices
+    for thr,ns in ((1,8),(5,24)):
+        pp=(ctypes.c_int32*5)(0,0,0,thr,ns)
+        words=i64(0); rc=L.hcspmm_plan_words(P(rp),i64(N),i64(E),P(bp),P(ht),pp,ctypes.byref(words)); assert rc==0
+        plan=np.zeros(max(words.value,64),np.int32)
+        rc=L.hcspmm_plan_build(P(rp),P(col),i64(N),i64(E),i64(N),P(bp),P(e2c),P(ht),pp,P(plan),i64(len(plan))); assert rc==0,rc
     n_ok+=1
 print('asan/ubsan host run ok:',n_ok,'graphs')

@@ -217,6 +217,7 @@ int forward_impl(const void* X, int64_t x_rows, int64_t ldx, void* Z, int64_t ld
     a.n_tasks = ph->n_tasks;
     a.n_tiny = ph->n_tiny;
     a.tiny_wgs = 0;
+    a.tiny_kernel_wgs = 0;
     a.off_slice_table = ph->off_slice_table;
     a.off_slice_tasks = ph->off_slice_tasks;
     a.n_slices = ph->n_slices;

@@ -781,6 +781,38 @@ __global__ __launch_bounds__(kThreads, MINW) void hybrid_plan_kernel(PlanArgs a)
   }
 }
 
+// Tiny tasks as their own launch (low-degree graphs: most rows of the paper's Table-II shapes hold at most two entries).
+// Inside the hybrid kernel the tiny region shares that kernel's register allocation (96 registers, five waves per SIMD);
+// this kernel holds nothing but the tiny-task state -- 56-64 registers, eight waves per SIMD.  Measured
+// (profiles/r03/ab_tiny_kernel.log): 2-4 % on the RD / TT / YeastH-sized graphs with T = 2 tasks per lane group; T = 4
+// is no better and T = 8 (96 registers, five waves) 25 % worse -- the launch is NOT short of loads in flight.  What it is
+// bound by (profiles/r03/lowdeg_floor.log, RD-sized, D = 32): descriptors + Z stores alone 104 us (a Z-sized fill: 89),
+// + every gather an L2 hit 183 us, + the real 622 MB X 321 us = 1.65 GB at 5.1 TB/s of random 128-byte lines mixed with
+// stores, 0.8 of what the guide calls achievable for STREAMING.  Bytes are within 1.2x of compulsory: nothing left to fuse.
+// Taken when the plan has enough tiny tasks to fill the chip (launch_plan_LV); small graphs keep the in-kernel region
+// and its single launch.  Same order of additions: same bits.
+#ifndef HCSPMM_TINY_KERNEL_T
+#define HCSPMM_TINY_KERNEL_T 2
+#endif
+#ifndef HCSPMM_TINY_KERNEL_WAVES
+#define HCSPMM_TINY_KERNEL_WAVES 8
+#endif
+#ifndef HCSPMM_TINY_KERNEL_MIN_TASKS
+#define HCSPMM_TINY_KERNEL_MIN_TASKS 262144  // fewer tiny tasks than this stay in the hybrid launch (one launch less)
+#endif
+template <typename E, int L, int VEC>
+__global__ __launch_bounds__(kThreads, HCSPMM_TINY_KERNEL_WAVES) void tiny_kernel(PlanArgs a) {
+  constexpr int R = 64 / L, T = HCSPMM_TINY_KERNEL_T;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int p = (int)blockIdx.x / a.tiny_kernel_wgs;
+  const int b = (int)blockIdx.x - p * a.tiny_kernel_wgs;
+  const int c0 = p * a.panel_cols;
+  const int first = a.n_tasks - a.n_tiny + (b * kWaves + wave) * (R * T);
+  if (first >= a.n_tasks) return;
+  tiny_tasks<E, L, VEC, T>(a, first, c0, min(a.D, c0 + a.panel_cols), lane);
+}
+
 // Fix-up: rows that were split into segments -- Z[row] = sum of its partial rows, in a fixed order
 // (deterministic): one wave per split row; its 64/L lane groups (L = lanes a row needs) take every (64/L)-th
 // segment with eight loads in flight and are combined by the same xor-shuffle tree as a wide task.  A hub of
@@ -944,7 +976,14 @@ static hipError_t launch_plan_LV(const PlanArgs& a, hipStream_t stream) {
   PlanArgs b = a;
   b.n_wide = (R > 1) ? a.n_wide : 0;  // with one lane group per wave a wide task is an ordinary one
   b.wide_wgs = (b.n_wide + kWaves - 1) / kWaves;
-  b.tiny_wgs = (a.n_tiny + kWaves * R * TinyT<L>::value - 1) / (kWaves * R * TinyT<L>::value);
+  // tiny tasks: a region of the hybrid launch, or -- when there are enough of them -- a launch of their own behind it
+  static const int tiny_kernel_min = [] {
+    const char* e = getenv("HCSPMM_TINY_KERNEL_MIN_TASKS");
+    return e ? atoi(e) : HCSPMM_TINY_KERNEL_MIN_TASKS;
+  }();
+  const bool own_tiny_launch = !a.fused && tiny_kernel_min >= 0 && a.n_tiny >= tiny_kernel_min && a.n_tiny > 0;
+  b.tiny_kernel_wgs = own_tiny_launch ? (a.n_tiny + kWaves * R * HCSPMM_TINY_KERNEL_T - 1) / (kWaves * R * HCSPMM_TINY_KERNEL_T) : 0;
+  b.tiny_wgs = own_tiny_launch ? 0 : (a.n_tiny + kWaves * R * TinyT<L>::value - 1) / (kWaves * R * TinyT<L>::value);
   b.free_wgs_pp = b.wide_wgs + (a.n_tasks - a.n_tiny - b.n_wide + kWaves * R - 1) / (kWaves * R) + b.tiny_wgs;
   // the sliced region: per XCD ceil(slice_xcd_tasks / tasks per workgroup) workgroups, interleaved b = x (mod 8); a panel is
   // padded to a multiple of 8 workgroups so that b mod 8 == blockIdx mod 8 in every panel (the idle ones return at once)
@@ -994,6 +1033,11 @@ static hipError_t launch_plan_LV(const PlanArgs& a, hipStream_t stream) {
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
+  if (b.tiny_kernel_wgs > 0) {
+    hipLaunchKernelGGL((tiny_kernel<E, L, VEC>), dim3((unsigned)(b.tiny_kernel_wgs * n_col_panels)), dim3(kThreads), 0, stream, b);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
   if (a.n_split_rows > 0) {
     const int fg = (a.n_split_rows + kWaves - 1) / kWaves;
     hipLaunchKernelGGL((fixup_kernel<E, VEC>), dim3(fg), dim3(kThreads), 0, stream, b);

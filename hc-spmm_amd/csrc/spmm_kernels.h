@@ -27,6 +27,7 @@ struct PlanArgs {
   int sparse_wgs_pp, dense_vec;        // filled by the launcher
   int wide_wgs, sparse_wgs, n_panels;  // filled by the launcher
   int tiny_wgs;                        // filled by the launcher: workgroups of the tiny-task region (per panel)
+  int tiny_kernel_wgs;                 // filled by the launcher: > 0 = the tiny tasks run as their own launch (per panel)
   // XCD-affine column slices (hcspmm.h n_slices): slice s owns descriptors [table[s], table[s+1]) of the slice task
   // list and is served by the workgroups b = s (mod 8) of the sliced region, the first slice_wgs of every panel
   int off_slice_table, off_slice_tasks, n_slices, slice_xcd_tasks;

@@ -46,6 +46,7 @@ for _p in (ROOT, os.path.join(ROOT, "hc-spmm_amd")):
 
 import numpy as np  # noqa: E402
 
+L2_PEAK_GBS = 34500.0  # MI355X_MICROARCH.md, L2 (per XCD): 4 MiB x 8, ~34.5 TB/s aggregate
 HBM_PEAK_GBS = 8000.0  # MI355X spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable streaming)
 FP32_MFMA_PEAK_TFLOPS = 157.3
 INFINITY_CACHE_BYTES = 256 << 20
@@ -279,6 +280,7 @@ def live_pmc(args, cache_dir, cases, passes):
         if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
             hit, miss = sum(c["TCC_HIT_sum"].values()), sum(c["TCC_MISS_sum"].values())
             e["l2_hit_rate"] = hit / max(hit + miss, 1.0)
+            e["l2_request_bytes"] = 128.0 * (hit + miss)  # 128-byte lines through the eight L2s per step
         if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
             # rocprofv3's MfmaUtil: MFMA-busy cycles summed over the SIMDs / (GPU-active cycles x SIMDs); GRBM_GUI_ACTIVE is
             # summed over the 8 XCDs (MI355X_MICROARCH.md, DVFS note).  The hybrid kernel only (the fix-up has no MFMA).
@@ -444,7 +446,16 @@ def run_case(fe, dev, workload, D, rp, col, n_local, world, rank, vworld, steps,
             "hip_graph_ms_per_step": graph_ms}
 
 
-def roofline_of(case, traffic=None, traffic_source=None):
+def fold_columns(rp, col, fold=2048):
+    """The same rows with every column id taken modulo `fold` (ascending inside a row, duplicates kept: same entry count,
+    same task lengths).  X then spans fold lines per 32-column panel -- 256 KB -- so every gather is an L2 hit and the launch
+    time that remains is the L2 -> CU gather path plus tasks, indices and stores: the floor of this degree sequence."""
+    rows = np.repeat(np.arange(len(rp) - 1, dtype=np.int64), np.diff(rp))
+    c2 = col.astype(np.int64) % fold
+    return c2[np.lexsort((c2, rows))].astype(np.int32)
+
+
+def roofline_of(case, traffic=None, traffic_source=None, l2_request_bytes=None, all_hit_ms=None):
     """The roofline block of one measured case (definitions: DESIGN.md section 5)."""
     h, D, N, E, elem = case["header"], case["D"], case["N"], case["E"], case["elem"]
     t = case["kernel_ms"] * 1e-3
@@ -478,7 +489,20 @@ def roofline_of(case, traffic=None, traffic_source=None):
                            "gathers that the caches served)")
     r["note"] = ("achieved = algorithmic bytes (every gathered X row counted, SURVEY 8d) / kernel time; when X fits the 256 MiB "
                  "Infinity Cache most gathers never reach HBM and achieved may exceed the HBM peak -- frac is therefore taken "
-                 "from the bytes that crossed the L2<->fabric boundary (PMC), which is what bounds the launch")
+                 "from the bytes that crossed the L2<->fabric boundary (PMC).  Since round 3 (XCD-affine column slices) the "
+                 "headline moves a third fewer bytes across the fabric in 17 % less time: frac fell because the numerator did, "
+                 "and the launch now sits against the L2 -> CU gather rate (block `l2`), not the fabric")
+    if l2_request_bytes or all_hit_ms:
+        # the other ceiling of a gather: with XCD-affine column slices most rows of the headline are served by L2, and the
+        # launch is bound by the L2 -> CU path, not by what crosses the fabric
+        r["l2"] = {"peak_gbs": L2_PEAK_GBS}
+        if l2_request_bytes:
+            r["l2"].update({"request_bytes": l2_request_bytes, "gbs": l2_request_bytes / t / 1e9,
+                            "frac_of_peak": l2_request_bytes / t / 1e9 / L2_PEAK_GBS})
+        if all_hit_ms:
+            r["l2"].update({"all_hit_kernel_ms": all_hit_ms, "frac_of_all_hit_floor": all_hit_ms / case["kernel_ms"],
+                            "all_hit_note": "the same rows and task schedule sizes with every column id folded into [0, 2048) (X = 256 KB per "
+                                            "panel: every gather an L2 hit), timed in this run: what the launch would take if nothing missed L2"})
     if h.n_dense:
         flops = 2.0 * 16.0 * float(h.dense_k_sum) * D  # exactly what the MFMA chain of every dense window executes
         r["dense_path"] = {"flops_per_launch": flops, "tflops": flops / t / 1e12,
@@ -703,7 +727,16 @@ def main():
                 traffic = rec.get("traffic_bytes")
                 source = "recorded: %s (builder rocprofv3 run, kernel_src_sha %s)" % (rec.get("source"), rec.get("kernel_src_sha"))
                 extra = {"l2_hit_rate": rec.get("l2_hit_rate")}
-        roof = roofline_of(case, traffic, source)
+        all_hit_ms = None
+        if world == 1 and not strong and not args.no_sweep and not args.no_plan and len(col) <= 64_000_000:
+            try:  # the L2 gather floor of this degree sequence (a few seconds: one sort on the host, 20 steps)
+                floor = run_case(fe, dev, args.workload, D, rp, fold_columns(rp, col), n_local, 1, 0, vworld, 20, 5, args.dtype, 2,
+                                 False, 0, None, prep_runs=1)
+                all_hit_ms = floor["kernel_ms"]
+                del floor
+            except Exception:  # reported as absent, never fatal
+                all_hit_ms = None
+        roof = roofline_of(case, traffic, source, (pmc or {}).get(key, {}).get("l2_request_bytes") if pmc else None, all_hit_ms)
         roof.update({k: v for k, v in extra.items() if v is not None})
         if pmc and "error" in pmc:
             roof["pmc_error"] = pmc["error"]

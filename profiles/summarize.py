@@ -49,8 +49,13 @@ def main():
     main_k = [k for k in pmc if "hybrid" in k]
     if main_k:
         m = pmc[main_k[0]]
-        fetch_b = 2.0 * m.get("FETCH_SIZE", 0.0) * 1024.0
-        write_b = m.get("WRITE_SIZE", 0.0) * 1024.0
+        # a step = the hybrid launch + (low-degree graphs) the tiny-task launch + the fix-up: traffic and L2 requests are
+        # summed over all of them (as bench.py's live passes do); MFMA counters are the hybrid kernel's
+        step = [v for k, v in pmc.items() if "hcspmm::" in k]
+        fetch_b = 2.0 * sum(v.get("FETCH_SIZE", 0.0) for v in step) * 1024.0
+        write_b = sum(v.get("WRITE_SIZE", 0.0) for v in step) * 1024.0
+        m = dict(m, TCC_HIT_sum=sum(v.get("TCC_HIT_sum", 0.0) for v in step), TCC_MISS_sum=sum(v.get("TCC_MISS_sum", 0.0) for v in step)) \
+            if "TCC_HIT_sum" in m else m
         out["traffic_bytes_per_launch"] = fetch_b + write_b
         out["fetch_bytes_corrected"] = fetch_b
         out["write_bytes"] = write_b
@@ -69,10 +74,11 @@ def main():
         tpath = os.path.join(here, "measured.json")
         t = json.load(open(tpath)) if os.path.exists(tpath) else {}
         kern = [v for k, v in out["kernels"].items() if "hybrid" in k]
+        step_ms = sum(v["avg_ns"] for k, v in out["kernels"].items() if "hcspmm::" in k) / 1e6
         t[key] = {"traffic_bytes": fetch_b + write_b, "fetch_bytes": fetch_b, "write_bytes": write_b,
                   "l2_hit_rate": out.get("l2_hit_rate"), "mfma_util_percent": out.get("mfma_util_percent"),
                   "mfma_flops_per_launch": out.get("mfma_flops_per_launch"),
-                  "kernel_ms": (kern[0]["avg_ns"] / 1e6) if kern else None,
+                  "kernel_ms": (kern[0]["avg_ns"] / 1e6) if kern else None, "step_kernels_ms": step_ms,
                   "source": os.path.relpath(os.path.join(dst, "%s_summary.json" % key), os.path.dirname(here)),
                   "kernel_src_sha": bench.kernel_src_sha()}
         json.dump(t, open(tpath, "w"), indent=1, sort_keys=True)

@@ -63,6 +63,10 @@ def test_fp32_planned_kernels_keep_five_waves_per_simd(usage):
         assert u["scratch"] <= (20 if a[2] == 4 else 24), (a, u)
     for n, u in fused.items():
         assert u["occupancy"] >= 4 and u["scratch"] <= 24, (_demangled_args(n), u)
+    tiny = {n: u for n, u in usage.items() if "tiny_kernel" in n}
+    assert len(tiny) == 15
+    for n, u in tiny.items():  # the tiny-task launch exists for its occupancy: eight waves per SIMD, nothing spilled
+        assert u["occupancy"] >= 8 and u["scratch"] == 0, (n, u)
     for n, u in usage.items():
         if "fixup_kernel" in n:
             assert u["scratch"] == 0 and u["occupancy"] >= 5, (n, u)

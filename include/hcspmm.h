@@ -5,7 +5,8 @@
  * Every entry point names the reference interface it replaces (file:line under
  * the reference tree; "K.cu" = hybrid_kernel/hybrid_all_kernel.cu, "B.cpp" =
  * hybrid_kernel/hybrid_all.cpp).  The ABI is plain C: raw pointers, sizes and a
- * HIP stream; no torch types, no exceptions, no global mutable state.  All
+ * HIP stream; no torch types, no exceptions, no global mutable state (this describes the C ABI: the two Python-visible
+ * front-ends above it each keep a process-wide, weakly-referencing registry of the plans they made).  All
  * functions return HCSPMM_OK (0) or a negative code; hcspmm_strerror() names it.
  *
  * Pointer naming: *_h = host memory, *_d = device (HBM) memory.

@@ -64,7 +64,7 @@ def main():
         rp, col = random_graph(rng)
         N = len(rp) - 1
         D = int(rng.choice([1, 2, 3, 4, 7, 8, 16, 20, 22, 31, 32, 33, 40, 64, 96, 100, 128, 130, 256, 260]))
-        mode = str(rng.choice(["rule0", "rule2", "rule3", "rule4", "all_dense", "all_sparse", "plan_free", "tiny_splits"]))
+        mode = str(rng.choice(["rule0", "rule2", "rule3", "rule4", "all_dense", "all_sparse", "plan_free", "tiny_splits", "slices", "slices"]))
         dtype = [torch.float32, torch.float16, torch.bfloat16][int(rng.integers(0, 3))]
         rule = {"rule2": 2, "rule3": 3, "rule4": 4}.get(mode, 0)
         fe = frontends.get(["ctypes", "extension"][int(rng.integers(0, 2))])
@@ -72,12 +72,17 @@ def main():
         if mode == "tiny_splits":  # rows longer than 5 entries are cut into segments of 1..5
             g.row_nzr = fe.build_plan(g.rp_d, g.col_d, g.bp, g.e2c, g.ht, split_threshold=int(rng.integers(2, 6)),
                                       segment_len=int(rng.integers(1, 6)))
+        slice_kw = {}
+        if mode == "slices":  # XCD-affine column slices forced on: rows longer than 1..40 entries cut at 8..32 column boundaries
+            slice_kw = dict(slice_threshold=int(rng.choice([1, 2, 5, 16, 40])), n_slices=int(rng.choice([8, 16, 24, 32])))
+            seg = int(rng.choice([0, 0, 3, 16]))
+            g.row_nzr = fe.build_plan(g.rp_d, g.col_d, g.bp, g.e2c, g.ht, segment_len=seg, split_threshold=2 * seg, **slice_kw)
         X = rng.standard_normal((N, D)).astype(np.float32)
         strided = mode != "plan_free" and rng.random() < 0.3  # X and Z as column slices of wider matrices
         fused = dtype == torch.float32 and mode != "plan_free" and not strided and rng.random() < 0.35
         in_launch = fused and rng.random() < 0.6
         if in_launch:  # the same classification, plan flagged so that dense windows update inside the hybrid launch
-            g.row_nzr = fe.build_plan(g.rp_d, g.col_d, g.bp, g.e2c, g.ht, fuse_in_launch=True)
+            g.row_nzr = fe.build_plan(g.rp_d, g.col_d, g.bp, g.e2c, g.ht, fuse_in_launch=True, **slice_kw)
         tag = "%s/%s%s%s/%s" % (mode, str(dtype).replace("torch.", ""), "/strided" if strided else "",
                                 ("/fused_in_launch" if in_launch else "/fused") if fused else "", fe.name)
 

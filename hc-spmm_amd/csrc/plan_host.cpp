@@ -51,6 +51,7 @@ namespace {
 constexpr int kSliceAuto = 0, kSliceOn = 1, kSliceOff = -1;
 constexpr int32_t kSliceAutoThreshold = 256;      // rows longer than this are sliced: flat optimum 192-256 on every workload (profiles/r03/ab_slices.log)
 constexpr int64_t kSliceAutoMinColumns = 65536;  // a 128-byte line per X row: below this a panel of X is within two L2s anyway
+constexpr int kSliceSample = 4;                  // the boundary histogram looks at every 4th entry of the long rows
 constexpr int kSlicePad = 64;                    // slice lists are padded to whole waves of any lane-group count (4 waves x 16)
 
 struct Resolved {
@@ -86,18 +87,26 @@ inline int64_t pieces_bound(int64_t d, const Resolved& rp) {
   return std::min<int64_t>(d, rp.n_slices - 1 + (d + rp.segment_len - 1) / rp.segment_len);
 }
 
-// The pieces of one sliced row: entries [e0, e0 + d) cut where the (ascending) column ids cross bounds[0 .. S-2]
-// (bounds[s] = first column id of slice s + 1) and every seg entries.  fn(slice, first entry, length), in CSR order.
+// Cut points of one sliced row: cuts[s] = offset (in [0, d]) of the first entry of slice s, cuts[S] = d; entries
+// [e0, e0 + d) are cut where the (ascending) column ids cross bounds[0 .. S-2] (bounds[s] = first column id of slice s + 1).
 // Unsorted columns still give a partition of the row (placement loses its meaning, the sum does not).
-template <typename F>
-inline void for_each_piece(const int32_t* col, int32_t e0, int64_t d, const int32_t* bounds, int S, int32_t seg, F fn) {
+inline void slice_cuts(const int32_t* col, int32_t e0, int64_t d, const int32_t* bounds, int S, int32_t* cuts) {
   const int32_t* first = col + e0;
   int64_t lo = 0;
-  for (int s = 0; s < S && lo < d; ++s) {
+  cuts[0] = 0;
+  for (int s = 0; s < S; ++s) {
     const int64_t hi = (s == S - 1) ? d : std::lower_bound(first + lo, first + d, bounds[s]) - first;
-    for (int64_t b = lo; b < hi; b += seg) fn(s, (int32_t)(e0 + b), (int32_t)std::min<int64_t>(seg, hi - b));
+    cuts[s + 1] = (int32_t)hi;
     lo = hi;
   }
+}
+
+// The pieces of one sliced row from its cut points: every slice's range, cut every seg entries.
+// fn(slice, first entry, length), in CSR order.
+template <typename F>
+inline void for_each_piece(const int32_t* cuts, int32_t e0, int S, int32_t seg, F fn) {
+  for (int s = 0; s < S; ++s)
+    for (int64_t b = cuts[s]; b < cuts[s + 1]; b += seg) fn(s, (int32_t)(e0 + b), (int32_t)std::min<int64_t>(seg, cuts[s + 1] - b));
 }
 
 inline int64_t align4(int64_t x) { return (x + 3) & ~int64_t(3); }
@@ -329,7 +338,7 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
         if (ht[w] != 0 && rowptr[r1] > rowptr[r0]) continue;
         for (int64_t r = r0; r < r1; ++r) {
           if ((int64_t)rowptr[r + 1] - rowptr[r] <= rp.slice_threshold) continue;
-          for (int64_t e = rowptr[r]; e < rowptr[r + 1]; ++e) h[col[e] >> shift]++;
+          for (int64_t e = rowptr[r]; e < rowptr[r + 1]; e += kSliceSample) h[col[e] >> shift]++;  // (a sample: balance needs no more)
         }
       }
     });
@@ -357,10 +366,14 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
   struct Counts {
     std::vector<int64_t> cls;
     std::vector<int64_t> slice_cls;  // [slice][class]
+    std::vector<int32_t> cuts;       // S + 1 cut points per sliced row of this thread's range, in walk order (pass 1 -> pass 2)
     int64_t n_fix = 0, n_slots = 0, n_dense = 0, n_sparse_w = 0;
   };
   std::vector<Counts> cnt((size_t)T);
-  auto walk = [&](int t, auto&& on_task, auto&& on_fix, auto&& on_dense, auto&& on_sparse_window, auto&& on_piece) {
+  auto walk = [&](int t, bool first_pass, auto&& on_task, auto&& on_fix, auto&& on_dense, auto&& on_sparse_window, auto&& on_piece) {
+    std::vector<int32_t>& row_cuts = cnt[(size_t)t].cuts;
+    if (first_pass) row_cuts.clear();
+    size_t next_cuts = 0;
     for (int64_t w = cut[(size_t)t]; w < cut[(size_t)t + 1]; ++w) {
       const int64_t r0 = w * HCSPMM_BLK_H, r1 = std::min<int64_t>(r0 + HCSPMM_BLK_H, N);
       const int64_t nnz = (int64_t)rowptr[r1] - rowptr[r0];
@@ -374,10 +387,16 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
         const int64_t d = (int64_t)rowptr[r + 1] - e0;
         if (slicing && d > rp.slice_threshold) {
           // a row that falls into one piece needs no partial sum; otherwise its pieces take consecutive slots in CSR order
+          if (first_pass) {  // the binary searches are done once: pass 2 reads the cut points back
+            row_cuts.resize(next_cuts + (size_t)S + 1);
+            slice_cuts(col, e0, d, bounds.data(), S, row_cuts.data() + next_cuts);
+          }
+          const int32_t* cuts = row_cuts.data() + next_cuts;
+          next_cuts += (size_t)S + 1;
           int64_t pcs = 0, k = 0;
-          for_each_piece(col, e0, d, bounds.data(), S, rp.segment_len, [&](int, int32_t, int32_t) { ++pcs; });
+          for (int sl = 0; sl < S; ++sl) pcs += ((int64_t)cuts[sl + 1] - cuts[sl] + rp.segment_len - 1) / rp.segment_len;
           const int64_t slot0 = pcs > 1 ? on_fix(r, pcs) : -1;
-          for_each_piece(col, e0, d, bounds.data(), S, rp.segment_len, [&](int sl, int32_t first, int32_t len) {
+          for_each_piece(cuts, e0, S, rp.segment_len, [&](int sl, int32_t first, int32_t len) {
             on_piece(sl, (int32_t)r, first, len, (int32_t)(pcs > 1 ? slot0 + k : -1));
             ++k;
           });
@@ -398,7 +417,7 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
     Counts& c = cnt[(size_t)t];
     c.cls.assign((size_t)n_cls, 0);
     c.slice_cls.assign((size_t)S * (size_t)n_cls, 0);
-    walk(t, [&](int32_t, int32_t, int32_t len, int32_t) { c.cls[(size_t)length_class(len)]++; },
+    walk(t, true, [&](int32_t, int32_t, int32_t len, int32_t) { c.cls[(size_t)length_class(len)]++; },
          [&](int64_t, int64_t segs) { c.n_fix++; c.n_slots += segs; return (int64_t)0; },
          [&](int64_t) { c.n_dense++; }, [&](int64_t) { c.n_sparse_w++; },
          [&](int sl, int32_t, int32_t, int32_t len, int32_t) { c.slice_cls[(size_t)sl * (size_t)n_cls + (size_t)length_class(len)]++; });
@@ -477,7 +496,7 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
     std::vector<int64_t>& p = pos[(size_t)t];
     std::vector<int64_t>& sp = spos[(size_t)t];
     int64_t n_fix = fix_at[(size_t)t], slot = slot_at[(size_t)t], nd = dense_at[(size_t)t], nsw = sparse_w_at[(size_t)t];
-    walk(t,
+    walk(t, false,
          [&](int32_t row, int32_t e0, int32_t len, int32_t slot_id) {
            const int64_t q = p[(size_t)length_class(len)]++;
            if (len <= HCSPMM_TINY_LEN) {  // classes 2, 1, 0: the tail of the list

@@ -13,7 +13,7 @@ from hypothesis import strategies as st
 import hcspmm
 from hcspmm.capi import Header
 
-from test_host_cpu import _decode_plan, _expand_tiny
+from test_host_cpu import _decode_plan, _decode_slices, _expand_tiny
 
 
 @st.composite
@@ -99,6 +99,53 @@ def test_plan_covers_every_entry_exactly_once(capi, g, mode, split, seg):
     assert sorted(fix[:, 0].tolist()) == long_rows
     for row, s0, ns, _ in fix:
         assert ns == -(-deg[row] // min(seg, split))
+
+
+@settings(**SETTINGS)
+@given(csr_graphs(), st.sampled_from([0, 2]), st.integers(1, 9), st.sampled_from([8, 16, 24, 64]), st.sampled_from([0, 1, 3, 7]))
+def test_sliced_plan_covers_every_entry_exactly_once(capi, g, rule, thr, S, seg):
+    """XCD-affine column slices forced on ragged graphs: free tasks + slice pieces + dense windows cover every stored entry
+    exactly once; a slice's pieces lie in its own ascending column range; a row's pieces take consecutive partial slots in
+    CSR order; the header's counts are the real ones (the blob is sized by upper bounds)."""
+    rp, col = g
+    N, E = len(rp) - 1, len(col)
+    W = (N + 15) // 16
+    bp, e2c, e2r, ht, _, _ = hcspmm.preprocess(torch.from_numpy(col), torch.from_numpy(rp), N, E, W, rule=rule)
+    plan = hcspmm.build_plan(torch.from_numpy(rp), torch.from_numpy(col), bp, e2c, ht, slice_threshold=thr, n_slices=S,
+                             segment_len=seg, split_threshold=2 * seg).numpy()
+    h, tasks, dindex, fix = _decode_plan(plan)
+    assert capi.lib().hcspmm_plan_check(ctypes.byref(h), N, E, len(plan)) == 0 and h.total_words == len(plan)
+    deg = np.diff(rp)
+    win_nnz = np.array([rp[min(16 * w + 16, N)] - rp[16 * w] for w in range(W)])
+    dense_rows = np.repeat((ht.numpy() != 0) & (win_nnz > 0), 16)[:N]
+    n_long = int(((deg > thr) & ~dense_rows).sum())
+    assert h.n_slices == (S if n_long else 0) and h.n_sliced_rows == n_long
+    table, slices = _decode_slices(plan, h)
+    cover = np.zeros(E, np.int32)
+    for row, e0, ln, slot in _expand_tiny(h, tasks, fix, rp, col):
+        assert deg[row] <= thr or h.n_slices == 0
+        cover[e0:e0 + ln] += 1
+    ranges, pieces = [], {}
+    for d in slices:
+        if len(d):
+            ranges.append((int(col[d[:, 1]].min()), int(col[d[:, 1] + d[:, 2] - 1].max())))
+        for row, e0, ln, slot in d:
+            assert deg[row] > thr and rp[row] <= e0 and e0 + ln <= rp[row + 1]
+            cover[e0:e0 + ln] += 1
+            pieces.setdefault(int(row), []).append((int(e0), int(ln), int(slot)))
+    for w in dindex[:, 0]:
+        cover[rp[16 * w]:rp[min(16 * w + 16, N)]] += 1
+    assert np.all(cover == 1)
+    assert all(a[1] < b[0] for a, b in zip(ranges, ranges[1:]))
+    fixmap = {int(r): (int(s0), int(ns)) for r, s0, ns, _ in fix}
+    for row, ps in pieces.items():
+        ps.sort()
+        if len(ps) == 1:
+            assert ps[0][2] == -1 and row not in fixmap
+        else:
+            s0, ns = fixmap[row]
+            assert ns == len(ps) and [q[2] for q in ps] == list(range(s0, s0 + ns))
+    assert h.nnz_sliced == int(deg[(deg > thr) & ~dense_rows].sum()) if h.n_slices else h.nnz_sliced == 0
 
 
 @settings(**SETTINGS)

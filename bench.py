@@ -626,7 +626,9 @@ def main():
     cache_dir = args.graph_cache
     own_cache = False
     do_sweep = world == 1 and not args.no_sweep and not strong and not args.pmc_child
-    do_pmc = world == 1 and not args.pmc_child and not args.no_pmc and not strong
+    # (a strong-scaling graph on one GPU gets its counter passes too, up to 100 M entries: beyond that the passes' second copy
+    # of the graph on the host and their run time are not worth a `traffic` figure)
+    do_pmc = world == 1 and not args.pmc_child and not args.no_pmc and not (strong and STRONG_WORKLOADS[args.workload][1] // max(1, args.strong_scale) > 100_000_000)
     if do_pmc and not cache_dir:
         cache_dir = tempfile.mkdtemp(prefix="hcspmm_bench_")
         own_cache = True
@@ -638,6 +640,8 @@ def main():
             f_rp, f_col = (os.path.join(cache_dir, "%s_%s.npy" % (wl, n)) for n in ("rp", "col")) if cache_dir else (None, None)
             if cache_dir and os.path.exists(f_col):
                 graphs_host[wl] = (np.load(f_rp), np.load(f_col))
+            elif wl in STRONG_WORKLOADS:
+                raise SystemExit("bench.py: strong-scaling graph %s is not in the graph cache" % wl)
             else:
                 nl, el, _, vw, _ = WORKLOADS[wl]
                 w = world * vworld if wl == args.workload else vw
@@ -648,9 +652,16 @@ def main():
                     np.save(f_col, graphs_host[wl][1])
         return graphs_host[wl]
 
-    if strong:
+    if strong and args.pmc_child:
+        rp, col = graph_of(args.workload)  # written by the parent
+        n_local = n_total = len(rp) - 1
+    elif strong:
         rp, col, n_local, n_total = make_strong_block(args.workload, world, rank, scale=max(1, args.strong_scale))
-        e_local = len(col)
+        if do_pmc:
+            graphs_host[args.workload] = (rp, col)
+            os.makedirs(cache_dir, exist_ok=True)
+            np.save(os.path.join(cache_dir, "%s_rp.npy" % args.workload), rp)
+            np.save(os.path.join(cache_dir, "%s_col.npy" % args.workload), col)
     else:
         rp, col = graph_of(args.workload)
     sweep_plan = [(w, d) for w, d in SWEEP_PLAN if not (w == args.workload and d == D)] if do_sweep else []
@@ -692,8 +703,8 @@ def main():
     if args.pmc_child:
         # one process, every case in turn, ONE preprocess each (its edge_to_row_kernel launch marks the case in the counter output)
         for i, (w, d) in enumerate(cases):
-            nl, _, _, vw, _ = WORKLOADS[w]
             rp_c, col_c = graph_of(w)
+            nl, vw = (len(rp_c) - 1, 1) if w in STRONG_WORKLOADS else (WORKLOADS[w][0], WORKLOADS[w][3])
             head = i == 0 and w == args.workload
             run_case(fe, dev, w, d, rp_c, col_c, nl, 1, 0, vworld if head else vw, args.steps, args.warmup,
                      args.dtype if head else "f32", args.rule if head else 0, args.no_plan if head else False, 0, None, prep_runs=1)

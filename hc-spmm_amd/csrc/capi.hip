@@ -73,7 +73,13 @@ static int panel_choice(const hcspmm_plan_header* h, int D, int dtype) {
   const int line_cols = 128 / elem_bytes(dtype);  // 32 fp32 or 64 16-bit columns: one cache line per gathered row
   if (D < 2 * line_cols || h->n_tasks <= 0) return D;
   const double mean_len = (double)h->nnz_sparse / ((double)h->n_tasks + (double)h->n_slice_tasks);
-  return mean_len >= 8.0 ? line_cols : D;
+  if (mean_len < 8.0) return D;
+  // an X beyond the 256 MiB Infinity Cache is gathered from HBM whatever the order: two lines per row and pass (256
+  // contiguous bytes per gather) measure 2-3 % faster there than one (config 4 / 5 shares, 16 M-node power law:
+  // profiles/r03/ab_panel_width.log), while a cache-resident X wants exactly one (Reddit-scale: 64 columns +8 %, all 128 +20 %)
+  const double x_bytes = (double)h->num_columns * (double)D * (double)elem_bytes(dtype);
+  const int cols = x_bytes > 256.0 * 1048576.0 ? 2 * line_cols : line_cols;
+  return D >= 2 * cols ? cols : D;
 }
 
 // Wide-task threshold.  A lane group sums a task with U loads in flight, so a task of T entries is a

@@ -23,7 +23,8 @@ Prints ONE JSON line on rank 0 (contract in the task description).  At N = 1 the
     is used and labelled with its source; failing that, the compulsory-bytes fraction.
   * `sweep`: the other BASELINE points timed in the same process -- Reddit-scale at dim 32 and 256, the
     Cora-scale config 2, one GPU's share of config 4 (dim 256) and one GPU's share of config 5 as SURVEY.md 8(d)
-    defines it (planted <= 24-column groups over 16 M columns: most windows on the dense-tile / MFMA path) -- each
+    defines it (planted <= 24-column groups over 16 M columns: most windows on the dense-tile / MFMA path), plus an
+    RD-sized low-degree graph (the paper's Table II) and the all-dense MFMA-utilisation probe -- each
     with ITS counters from the same child passes (one rocprofv3 run per counter set covers every workload);
   * `cpu_baseline`: torch.sparse.mm on the box's host cores (threads stated), the oracle port nested beside it.
 """
@@ -79,7 +80,8 @@ STRONG_WORKLOADS = {
     "c5": (250000 * 64, 4000000 * 64, 128, "BASELINE config 5 at full size (16 M nodes / 256 M entries; 70 % of the 16-row windows planted groups sharing 8-24 "
                                            "columns: dense-tile path under the reference's classifier), rows split over the ranks"),
 }
-SWEEP_PLAN = [("reddit", 32), ("reddit", 256), ("cora", 32), ("products_share", 256), ("c5_share", 128)]
+SWEEP_PLAN = [("reddit", 32), ("reddit", 256), ("cora", 32), ("products_share", 256), ("c5_share", 128),
+              ("rd_like", 32), ("alldense", 128)]  # + one of the paper's Table-II shapes (low degree) and the dense-tile / MFMA probe
 
 KERNEL_SOURCES = ["hc-spmm_amd/csrc/spmm_impl.h", "hc-spmm_amd/csrc/spmm_kernels.h", "hc-spmm_amd/csrc/capi.hip",
                   "hc-spmm_amd/csrc/plan_host.cpp", "hc-spmm_amd/csrc/preprocess_host.cpp", "include/hcspmm.h"]

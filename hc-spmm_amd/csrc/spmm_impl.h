@@ -16,7 +16,10 @@
 //    at a time across the whole grid; (c) column indices are fetched coalesced once per L
 //    neighbours and broadcast through the LDS crossbar (ds_bpermute); every lane issues 16-byte
 //    loads in branch-free batches of 8; (d) rows of at most two entries -- most rows of a low-degree
-//    graph -- are "tiny" tasks whose column indices travel inside the task descriptor.
+//    graph -- are "tiny" tasks whose column indices travel inside the task descriptor (their own launch, at eight
+//    waves per SIMD, when there are enough of them); (e) rows longer than 256 entries are cut into XCD-affine column
+//    slices: slice s is served only by workgroups b = s (mod 8), which share one XCD's L2, so that L2 sees 1/8 of the
+//    columns from those tasks -- the headline went from fabric-bound (52 % L2 hits) to L2-gather-bound (67 %).
 //  * dense-tile path: v_mfma_f32_16x16x4_f32 takes its B operand one fp32 per lane, so the
 //    gathered X rows go from HBM straight into MFMA operand registers with 16-byte loads (the
 //    VEC elements of a lane feed VEC MFMAs whose results re-assemble into one vector store);

@@ -48,7 +48,11 @@ def test_extension_forward_and_fused(HCSPMM, oracle_mod, D):
     rp, col = graphs.planted_dense_graph(1200, seed=5)
     N = len(rp) - 1
     rp_d, col_d = torch.from_numpy(rp).to(dev), torch.from_numpy(col).to(dev)
-    outs = HCSPMM.preprocess(col_d, rp_d, N, len(col), (N + 15) // 16)  # column_index FIRST (HC-SpMM_main.py:52)
+    HCSPMM.set_plan_params(0, 0, False, -1, 0)  # CSR-order bits asserted for every row below: no column slices
+    try:
+        outs = HCSPMM.preprocess(col_d, rp_d, N, len(col), (N + 15) // 16)  # column_index FIRST (HC-SpMM_main.py:52)
+    finally:
+        HCSPMM.set_plan_params(0, 0)
     want = oracle_mod.preprocess(rp, col, oracle_mod.RULE_INTENDED)
     for w, g in zip(want, outs[:4]):
         assert g.is_cuda and g.dtype == torch.int32 and np.array_equal(w, g.cpu().numpy())
@@ -95,10 +99,12 @@ def test_extension_as_shipped_rule_and_side_stream(HCSPMM, oracle_mod):
     N = len(rp) - 1
     rp_d, col_d = torch.from_numpy(rp).to(dev), torch.from_numpy(col).to(dev)
     HCSPMM.set_rule(2)
+    HCSPMM.set_plan_params(0, 0, False, -1, 0)  # CSR-order bits asserted for every row below: no column slices (explicit beats HCSPMM_SLICE_THRESHOLD)
     try:
         outs = HCSPMM.preprocess(col_d, rp_d, N, len(col), (N + 15) // 16)
     finally:
         HCSPMM.set_rule(0)
+        HCSPMM.set_plan_params(0, 0)
     assert int(outs[3].sum()) == 0  # hybrid_all_kernel.cu:262 as shipped: every window sparse
     X = np.random.default_rng(0).standard_normal((N, 64)).astype(np.float32)
     Xd = torch.from_numpy(X).to(dev)

@@ -39,7 +39,9 @@ def _t(a, dev=None):
 
 
 class Graph:
-    def __init__(self, rp, col, dev, rule=0, plan=True, force_type=None, fe=None):
+    def __init__(self, rp, col, dev, rule=0, plan=True, force_type=None, fe=None, no_slices=False):
+        """no_slices: the test asserts CSR-order bits (or plan counts) for EVERY row: build the plan without XCD-affine column
+        slices whatever HCSPMM_SLICE_THRESHOLD says (the stress run of this file forces them on everywhere else)."""
         self.fe = fe if fe is not None else frontends.get("ctypes")
         self.rp, self.col = rp, col
         self.N, self.E = len(rp) - 1, len(col)
@@ -50,6 +52,8 @@ class Graph:
             self.ht = torch.full_like(self.ht, force_type)
             if plan:  # ... and rebuild the plan for that classification
                 self.row_nzr = self.fe.build_plan(self.rp_d, self.col_d, self.bp, self.e2c, self.ht)
+        if plan and no_slices:
+            self.row_nzr = self.fe.build_plan(self.rp_d, self.col_d, self.bp, self.e2c, self.ht, slice_threshold=-1)
         if not plan:  # the reference's [0] placeholders -> plan-free kernel
             self.row_nzr = torch.zeros(1, dtype=torch.int32, device=dev)
 
@@ -365,7 +369,7 @@ def _tiny_graph(N=3000, seed=9):
 @pytest.mark.parametrize("D", [128, 64, 32, 20, 16, 6, 3, 1])
 def test_tiny_tasks_and_tiny_segments(oracle_mod, dev, fe, D):
     rp, col = _tiny_graph()
-    g = Graph(rp, col, dev, rule=2, fe=fe)  # every window on the sparse-row path
+    g = Graph(rp, col, dev, rule=2, fe=fe, no_slices=True)  # every window on the sparse-row path
     h = g.header()
     deg = np.diff(rp)
     assert h.n_tiny == int((deg <= 2).sum()) + 3 and h.n_split_rows == 3
@@ -479,7 +483,7 @@ def test_weight_grad_declines_unsupported(dev):
 
 def test_error_behaviour(oracle_mod, dev, fe):
     rp, col = graphs.powerlaw_graph(200, 900, seed=1)
-    g = Graph(rp, col, dev, fe=fe)
+    g = Graph(rp, col, dev, fe=fe, no_slices=True)
     X = torch.zeros(g.N, 16, device=dev)
     with pytest.raises(RuntimeError, match="input must be contiguous"):
         fe.forward(X.t().contiguous().t(), *g.args())
@@ -608,7 +612,7 @@ def test_offsets_beyond_2_to_31_elements(dev):
 def test_forward_into_strided_views(oracle_mod, dev, fe):
     """Strided operator: read a column panel of a wider X, write a column panel of a wider Z, in place."""
     rp, col = graphs.planted_dense_graph(1500, seed=4)  # both sub-paths
-    g = Graph(rp, col, dev, fe=fe)
+    g = Graph(rp, col, dev, fe=fe, no_slices=True)
     rng = np.random.default_rng(9)
     Xw = rng.standard_normal((g.N, 160)).astype(np.float32)
     Xd = _t(Xw, dev)
@@ -681,7 +685,7 @@ def test_config4_products_scale_full_size(oracle_mod, dev):
     rp, col = graphs.powerlaw_graph(2450000, 62000000, seed=4)
     assert len(rp) - 1 == 2450000 and abs(len(col) - 62000000) < 62000
     h = _full_size_properties(oracle_mod, dev, rp, col, 2450000, 256)
-    assert h.n_split_rows > 0 and h.n_tasks > 2000000
+    assert h.n_split_rows > 0 and h.n_tasks + h.n_slice_tasks > 2000000 and h.n_slices == 8
 
 
 def test_config5_share_dense_heavy(oracle_mod, dev):

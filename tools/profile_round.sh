@@ -24,4 +24,5 @@ declare -A W=( [reddit_d128]="" [reddit_d32]="--dim 32" [reddit_d256]="--dim 256
                [yh_like_d32]="--workload yh_like" [reddit_d128_bf16]="--dtype bf16" )
 KEYS="$@"
 [ -z "$KEYS" ] && KEYS="reddit_d128 reddit_d32 reddit_d256 cora_d32 products_share_d256 c5_share_d128 alldense_d128 rd_like_d32 yh_like_d32 reddit_d128_bf16"
-for n in $KEYS; do mkdir -p $OUT/$n; run $n ${W[$n]}; done
+# (gpurun merges new files into an existing gpurun_out/: clear this workload's directory first, or a later summary mixes rounds)
+for n in $KEYS; do rm -rf $OUT/$n; mkdir -p $OUT/$n; run $n ${W[$n]}; done

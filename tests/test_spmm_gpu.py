@@ -517,6 +517,8 @@ def test_error_behaviour(oracle_mod, dev, fe):
     tall = fe.preprocess(g.col_d, g.rp_d, g.N, g.E, (g.N + 15) // 16, num_columns=2 * g.N)
     with pytest.raises(RuntimeError, match="rows"):
         fe.forward(Xr, g.rp_d, g.col_d, *tall)
+    tall = list(tall)
+    tall[4] = fe.build_plan(g.rp_d, g.col_d, tall[0], tall[1], tall[3], num_columns=2 * g.N, slice_threshold=-1)  # (bits compared with Z)
     Zt = fe.forward_rect(torch.cat([Xr, Xr]), g.rp_d, g.col_d, *tall)[0]
     assert torch.equal(Zt, Z)
 

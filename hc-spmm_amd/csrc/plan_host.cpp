@@ -51,6 +51,10 @@ namespace {
 constexpr int kSliceAuto = 0, kSliceOn = 1, kSliceOff = -1;
 constexpr int32_t kSliceAutoThreshold = 256;      // rows longer than this are sliced: flat optimum 192-256 on every workload (profiles/r03/ab_slices.log)
 constexpr int64_t kSliceAutoMinColumns = 65536;  // a 128-byte line per X row: below this a panel of X is within two L2s anyway
+// ... and up to a quarter of a million columns (a panel of X within eight L2s) only launches with enough work gain: a
+// 40-70 us launch loses 3-17 % to the extra region and the longer fix-up (profiles/r03/ab_slices_midsize.log)
+constexpr int64_t kSliceAutoAlwaysColumns = 250000;
+constexpr int64_t kSliceAutoMinEntries = 3000000;
 constexpr int kSliceSample = 4;                  // the boundary histogram looks at every 4th entry of the long rows
 constexpr int kSlicePad = 64;                    // slice lists are padded to whole waves of any lane-group count (4 waves x 16)
 
@@ -296,7 +300,9 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
   if (rp.slice_mode != kSliceOff) {
     rc = compute_layout(rowptr, N, bp, ht, rp, true, &L);
     if (rc != HCSPMM_OK) return rc;
-    if (rp.slice_mode == kSliceAuto) slicing = M >= kSliceAutoMinColumns && L.nnz_sliced * 20 >= L.nnz_sparse && L.nnz_sliced > 0;
+    if (rp.slice_mode == kSliceAuto)
+      slicing = M >= kSliceAutoMinColumns && L.nnz_sliced * 20 >= L.nnz_sparse && L.nnz_sliced > 0 &&
+                (M >= kSliceAutoAlwaysColumns || L.nnz_sparse >= kSliceAutoMinEntries);
     if (L.n_sliced_rows == 0) slicing = false;
   }
   if (!slicing) {

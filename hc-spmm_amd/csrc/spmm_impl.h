@@ -801,7 +801,7 @@ __global__ __launch_bounds__(kThreads, MINW) void hybrid_plan_kernel(PlanArgs a)
 #define HCSPMM_TINY_KERNEL_WAVES 8
 #endif
 #ifndef HCSPMM_TINY_KERNEL_MIN_TASKS
-#define HCSPMM_TINY_KERNEL_MIN_TASKS 262144  // fewer tiny tasks than this stay in the hybrid launch (one launch less)
+#define HCSPMM_TINY_KERNEL_MIN_TASKS 524288  // fewer tiny tasks than this stay in the hybrid launch: even at 465 K, -15 % at 240 K, +3-4 % at 900 K (profiles/r03/ab_tiny_sizes.log)
 #endif
 template <typename E, int L, int VEC>
 __global__ __launch_bounds__(kThreads, HCSPMM_TINY_KERNEL_WAVES) void tiny_kernel(PlanArgs a) {

@@ -174,8 +174,9 @@ typedef struct hcspmm_plan_params {
                               hybrid launch (see there).  Default 0: measured on MI355X the two-launch form is 0-8 % faster
                               (profiles/r02/ab_fused.log) */
   int32_t slice_threshold; /* XCD-affine column slices: 0 = automatic (on for num_columns >= 65536 when at least 5 % of
-                              the sparse-path entries sit in rows longer than 256 entries; HCSPMM_SLICE_THRESHOLD in the
-                              environment overrides), > 0: rows longer than this are sliced, < 0: off */
+                              the sparse-path entries sit in rows longer than 256 entries and -- below 250 000 columns --
+                              the sparse path holds at least 3 M entries; HCSPMM_SLICE_THRESHOLD in the environment
+                              overrides), > 0: rows longer than this are sliced, < 0: off */
   int32_t n_slices;        /* 0 = 8 (HCSPMM_SLICES overrides); rounded up to a multiple of 8, at most 64 */
 } hcspmm_plan_params;
 

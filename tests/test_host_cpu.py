@@ -637,13 +637,16 @@ def test_plan_column_slices_layout():
 
 
 def test_plan_column_slices_automatic_rule():
-    """Automatic mode: on only when X spans many L2s (num_columns >= 65536) and the long rows hold >= 5 % of the entries."""
+    """Automatic mode: on only when X spans many L2s (num_columns >= 65536; below 250 000 columns only for >= 3 M sparse-path
+    entries) and the long rows hold >= 5 % of the entries."""
     rp, col = graphs.powerlaw_graph(3000, 90000, seed=5, max_degree_frac=0.3)
     bp, e2c, e2r, ht, plan, _ = _pre(rp, col, 2)
     assert _decode_plan(plan.numpy())[0].n_slices == 0  # 3000 columns
     plan = hcspmm.build_plan(torch.from_numpy(rp), torch.from_numpy(col), bp, e2c, ht, num_columns=70000).numpy()
+    assert _decode_plan(plan)[0].n_slices == 0  # 70 000 columns but only 90 K entries: a launch this small loses to the extra region
+    plan = hcspmm.build_plan(torch.from_numpy(rp), torch.from_numpy(col), bp, e2c, ht, num_columns=250000).numpy()
     h = _decode_plan(plan)[0]
     assert h.n_slices == 8 and h.slice_threshold == 256 and h.total_words == len(plan)
     rp2, col2 = graphs.uniform_graph(3000, 30000, seed=1)  # no long rows
     bp, e2c, e2r, ht, _, _ = _pre(rp2, col2, 2)
-    assert _decode_plan(hcspmm.build_plan(torch.from_numpy(rp2), torch.from_numpy(col2), bp, e2c, ht, num_columns=70000).numpy())[0].n_slices == 0
+    assert _decode_plan(hcspmm.build_plan(torch.from_numpy(rp2), torch.from_numpy(col2), bp, e2c, ht, num_columns=250000).numpy())[0].n_slices == 0

@@ -27,11 +27,17 @@ def main():
     import hcspmm
     dev = torch.device("cuda:0")
     for spec in args.workloads.split(","):
-        wl, D = spec.split(":")
-        D = int(D)
-        n_local, e_local, _, vw, _ = bench.WORKLOADS[wl]
         t0 = time.time()
-        rp, col = bench.make_local_block(wl, n_local, e_local, vw, 0)
+        if spec.startswith("pl:"):  # pl:N:E:D -- a square power-law graph of any size (mid-size points between configs 2 and 3)
+            _, n_local, e_local, D = spec.split(":")
+            wl, n_local, e_local, D, vw = spec, int(n_local), int(e_local), int(D), 1
+            from hcspmm import graphs
+            rp, col = graphs.powerlaw_graph(n_local, e_local, seed=3)
+        else:
+            wl, D = spec.split(":")
+            D = int(D)
+            n_local, e_local, _, vw, _ = bench.WORKLOADS[wl]
+            rp, col = bench.make_local_block(wl, n_local, e_local, vw, 0)
         N, E, M = len(rp) - 1, len(col), n_local * vw
         rp_d, col_d = torch.from_numpy(rp).to(dev), torch.from_numpy(col).to(dev)
         bp, e2c, e2r, ht, plan0, col_nzr = hcspmm.preprocess(col_d, rp_d, N, E, (N + 15) // 16, num_columns=M)

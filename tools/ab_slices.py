@@ -47,7 +47,9 @@ def main():
         print("== %s D=%d: N=%d E=%d columns=%d (graph %.0fs)" % (wl, D, N, E, M, time.time() - t0), flush=True)
         ref = None
         for v in args.variants.split(","):
-            if v == "off":
+            if v == "auto":
+                kw = {}
+            elif v == "off":
                 kw = dict(slice_threshold=-1)
             else:
                 parts = v.split("x")

@@ -70,6 +70,10 @@ static int panel_choice(const hcspmm_plan_header* h, int D, int dtype) {
   }();
   if (env < 0) return D;
   if (env > 0) return env >= D ? D : ((env + 15) / 16) * 16;
+  if (h->panel_cols != 0) {  // the plan's own choice (hcspmm_plan_params.panel_cols; hcspmm.tune_plan measures it)
+    const long long cols = h->panel_cols < 0 ? D : (long long)h->panel_cols * (4 / elem_bytes(dtype));
+    return cols >= D ? D : (int)cols;
+  }
   const int line_cols = 128 / elem_bytes(dtype);  // 32 fp32 or 64 16-bit columns: one cache line per gathered row
   if (D < 2 * line_cols || h->n_tasks <= 0) return D;
   const double mean_len = (double)h->nnz_sparse / ((double)h->n_tasks + (double)h->n_slice_tasks);

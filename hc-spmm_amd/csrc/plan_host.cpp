@@ -60,7 +60,7 @@ constexpr int kSlicePad = 64;                    // slice lists are padded to wh
 
 struct Resolved {
   int32_t split_threshold, segment_len, fuse_in_launch;
-  int32_t slice_mode, slice_threshold, n_slices;
+  int32_t slice_mode, slice_threshold, n_slices, panel_cols;
 };
 
 int env_int(const char* name, int dflt) {
@@ -69,7 +69,7 @@ int env_int(const char* name, int dflt) {
 }
 
 Resolved resolve(const hcspmm_plan_params* p) {
-  Resolved r{512, 256, 0, kSliceAuto, kSliceAutoThreshold, 8};
+  Resolved r{512, 256, 0, kSliceAuto, kSliceAutoThreshold, 8, 0};
   if (p) {
     if (p->split_threshold > 0) r.split_threshold = p->split_threshold;
     if (p->segment_len > 0) r.segment_len = p->segment_len;
@@ -82,6 +82,7 @@ Resolved resolve(const hcspmm_plan_params* p) {
   if (thr > 0) { r.slice_mode = kSliceOn; r.slice_threshold = thr; }
   else if (thr < 0) r.slice_mode = kSliceOff;
   if (ns > 0) r.n_slices = std::min(64, (ns + 7) / 8 * 8);
+  if (p && p->panel_cols != 0) r.panel_cols = p->panel_cols < 0 ? -1 : std::min(1 << 20, (p->panel_cols + 15) / 16 * 16);
   return r;
 }
 
@@ -633,6 +634,7 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
   h.slice_xcd_tasks = (int32_t)slice_xcd_tasks;
   h.nnz_sliced = slicing ? (int32_t)L.nnz_sliced : 0;
   h.n_sliced_rows = slicing ? (int32_t)L.n_sliced_rows : 0;
+  h.panel_cols = rp.panel_cols;
   static_assert(sizeof(hcspmm_plan_header) == HCSPMM_PLAN_HEADER_WORDS * 4, "header size");
   std::memcpy(plan, &h, sizeof(h));
   return HCSPMM_OK;

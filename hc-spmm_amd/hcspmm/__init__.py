@@ -25,7 +25,7 @@ __all__ = [
     "backward_fixed32", "backward_fixed32_fused", "backward_final_fused", "backward_fixed64",
     "backward_fixed64_fused", "backward_final_fused_64", "backward_GIN_final_fused", "loi_reorder",
     "apply_permutation", "weight_grad", "plan_header", "forward_rect", "forward_into", "wide_threshold", "workspace_bytes", "fused_in_launch", "build_plan", "set_default_rule", "RULE_INTENDED", "RULE_INTENDED_GUARD",
-    "RULE_AS_SHIPPED", "RULE_MI355X", "RULE_MI355X_WIDE", "mi355x_rule",
+    "RULE_AS_SHIPPED", "RULE_MI355X", "RULE_MI355X_WIDE", "mi355x_rule", "tune_plan",
 ]
 
 _DEFAULT_RULE = int(os.environ.get("HCSPMM_RULE", RULE_INTENDED))
@@ -254,17 +254,20 @@ def preprocess(column_index, row_pointers, num_nodes, num_edges, num_row_windows
 
 
 def build_plan(row_pointers, column_index, blockPartition, edgeToColumn, hybrid_type, device=None,
-               split_threshold=0, segment_len=0, num_columns=None, fuse_in_launch=False, slice_threshold=0, n_slices=0):
+               split_threshold=0, segment_len=0, num_columns=None, fuse_in_launch=False, slice_threshold=0, n_slices=0,
+               panel_cols=0):
     """Launch plan for an arbitrary window classification (e.g. every window forced onto one sub-path,
     or a classifier of the caller's own): -> plan tensor to pass as `row_nzr`.  fuse_in_launch: the fused
     operators update this plan's dense-tile windows inside the hybrid launch (include/hcspmm.h hcspmm_forward_fused).
-    slice_threshold / n_slices: XCD-affine column slices (hcspmm_plan_params; 0 = automatic, < 0 = off)."""
+    slice_threshold / n_slices: XCD-affine column slices (hcspmm_plan_params; 0 = automatic, < 0 = off).
+    panel_cols: feature columns per pass of the sparse-row path (0 = chosen at launch, < 0 = one pass; see tune_plan)."""
     L = lib()
     rp_h, col_h = _i32_host(row_pointers), _i32_host(column_index)
     bp_h, e2c_h, ht_h = _i32_host(blockPartition), _i32_host(edgeToColumn), _i32_host(hybrid_type)
     N, E = rp_h.numel() - 1, col_h.numel()
-    params = PlanParams(int(split_threshold), int(segment_len), int(bool(fuse_in_launch)), int(slice_threshold), int(n_slices)) \
-        if (split_threshold or segment_len or fuse_in_launch or slice_threshold or n_slices) else _PLAN_PARAMS
+    params = PlanParams(int(split_threshold), int(segment_len), int(bool(fuse_in_launch)), int(slice_threshold), int(n_slices),
+                        int(panel_cols)) \
+        if (split_threshold or segment_len or fuse_in_launch or slice_threshold or n_slices or panel_cols) else _PLAN_PARAMS
     words = ctypes.c_int64(0)
     check(L.hcspmm_plan_words(_ptr(rp_h), N, E, _ptr(bp_h), _ptr(ht_h), ctypes.byref(params), ctypes.byref(words)))
     plan = torch.empty(max(int(words.value), Header.WORDS), dtype=torch.int32)
@@ -276,6 +279,54 @@ def build_plan(row_pointers, column_index, blockPartition, edgeToColumn, hybrid_
     plan_d = plan.to(dev)
     _register(plan_d, h, row_pointers, column_index)
     return plan_d
+
+
+def tune_plan(row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, hybrid_type, embedding_dim,
+              dtype=torch.float32, num_columns=None, candidates=None, steps=20, fuse_in_launch=False):
+    """Measure, on this GPU and THIS graph, the plan variants whose best choice no size rule predicts -- column slices on /
+    off and the panel width of the sparse-row path -- and return (best plan tensor, report).  The automatic choices are tuned
+    on power-law graphs from 10 K to 16 M nodes; between them (e.g. 66 K-130 K nodes) another panel width can be 5-17 %
+    faster (profiles/r03/ab_panel_midsize.log, ab_slices_midsize.log).  Costs a handful of plan builds and
+    len(candidates) * (3 + steps) launches: worth it for a graph that will be multiplied thousands of times (training).
+    candidates: list of dicts of build_plan keywords (slice_threshold, n_slices, panel_cols, ...); default = slices
+    {automatic, off, 256 x 8} x panels {automatic, 32, 64, one pass} (panels only for embedding_dim >= 64).  The results of
+    all variants agree within the 1e-5 bar; rows short enough to be summed in CSR order by every variant agree bit for bit."""
+    dev = row_pointers.device
+    if not row_pointers.is_cuda:
+        raise RuntimeError("tune_plan measures on the GPU: graph tensors must be CUDA tensors")
+    D = int(embedding_dim)
+    N = row_pointers.size(0) - 1
+    M = N if num_columns is None else int(num_columns)
+    if candidates is None:
+        panels = [0, 32, 64, -1] if D >= 64 else [0]  # (fp32 columns: 16-bit features take twice as many per pass)
+        candidates = [dict(slice_threshold=s, panel_cols=p) for s in (0, -1, 256) for p in panels]
+    X = torch.randn(M, D, device=dev).to(dtype)
+    Z = torch.empty(N, D, dtype=dtype, device=dev)
+    col_nzr = torch.zeros(1, dtype=torch.int32, device=dev)
+    report, best, seen = [], None, set()
+    for kw in candidates:
+        plan = build_plan(row_pointers, column_index, blockPartition, edgeToColumn, hybrid_type, num_columns=M,
+                          fuse_in_launch=fuse_in_launch, **kw)
+        h = plan_header(plan)
+        key = (h.n_slices, h.slice_threshold, h.panel_cols, h.n_slice_tasks)
+        if key in seen:  # e.g. "slices off" on a graph the automatic rule leaves unsliced anyway
+            continue
+        seen.add(key)
+        ws = torch.empty(max(workspace_bytes(plan, D) // 4, 1), dtype=torch.float32, device=dev)
+        a = (row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, hybrid_type, plan, col_nzr)
+        for _ in range(3):
+            forward_into(X, Z, *a, workspace=ws)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(steps):
+            forward_into(X, Z, *a, workspace=ws)
+        e.record()
+        e.synchronize()
+        ms = s.elapsed_time(e) / steps
+        report.append(dict(kw, ms=ms, n_slices=h.n_slices))
+        if best is None or ms < best[0]:
+            best = (ms, plan)
+    return best[1], sorted(report, key=lambda r: r["ms"])
 
 
 def _check_input(t, name):

@@ -33,7 +33,7 @@ class Header(ctypes.Structure):
                                                                                   ("off_slice_table", ctypes.c_int32), ("off_slice_tasks", ctypes.c_int32),
                                                                                   ("n_slice_tasks", ctypes.c_int32), ("slice_xcd_tasks", ctypes.c_int32),
                                                                                   ("nnz_sliced", ctypes.c_int32), ("n_sliced_rows", ctypes.c_int32),
-                                                                                  ("reserved", ctypes.c_int32 * 19)]
+                                                                                  ("panel_cols", ctypes.c_int32), ("reserved", ctypes.c_int32 * 18)]
 
     @property
     def fingerprint(self):
@@ -43,7 +43,7 @@ class Header(ctypes.Structure):
 class PlanParams(ctypes.Structure):
     """hcspmm_plan_params."""
     _fields_ = [("split_threshold", ctypes.c_int32), ("segment_len", ctypes.c_int32), ("fuse_in_launch", ctypes.c_int32),
-                ("slice_threshold", ctypes.c_int32), ("n_slices", ctypes.c_int32)]
+                ("slice_threshold", ctypes.c_int32), ("n_slices", ctypes.c_int32), ("panel_cols", ctypes.c_int32)]
 
 
 # every exported symbol of include/hcspmm.h: name -> (restype, argtypes)

@@ -24,7 +24,7 @@ namespace {
   CHECK_CONTIGUOUS(x)
 
 int g_rule = HCSPMM_RULE_INTENDED;
-hcspmm_plan_params g_params = {0, 0, 0};
+hcspmm_plan_params g_params = {0, 0, 0, 0, 0, 0};
 
 void check_rc(int rc, const char* what) {
   TORCH_CHECK(rc == HCSPMM_OK, "HCSPMM.", what, ": ", hcspmm_strerror(rc), " [code ", rc, ", hipError_t ",
@@ -359,12 +359,12 @@ torch::Tensor spmm_forward_into(torch::Tensor input, torch::Tensor output, torch
 // build_plan: launch plan for an arbitrary window classification (e.g. every window forced onto one sub-path)
 torch::Tensor build_plan(torch::Tensor row_pointers, torch::Tensor column_index, torch::Tensor blockPartition,
                          torch::Tensor edgeToColumn, torch::Tensor hybrid_type, int split_threshold, int segment_len,
-                         int64_t num_columns, bool fuse_in_launch, int slice_threshold, int n_slices) {
+                         int64_t num_columns, bool fuse_in_launch, int slice_threshold, int n_slices, int panel_cols) {
   auto rp = to_host_i32(row_pointers), col = to_host_i32(column_index), bp = to_host_i32(blockPartition),
        e2c = to_host_i32(edgeToColumn), ht = to_host_i32(hybrid_type);
   const int64_t N = rp.numel() - 1, E = col.numel();
-  hcspmm_plan_params pp = (split_threshold || segment_len || fuse_in_launch || slice_threshold || n_slices)
-                              ? hcspmm_plan_params{split_threshold, segment_len, fuse_in_launch ? 1 : 0, slice_threshold, n_slices}
+  hcspmm_plan_params pp = (split_threshold || segment_len || fuse_in_launch || slice_threshold || n_slices || panel_cols)
+                              ? hcspmm_plan_params{split_threshold, segment_len, fuse_in_launch ? 1 : 0, slice_threshold, n_slices, panel_cols}
                               : g_params;
   int64_t words = 0;
   check_rc(hcspmm_plan_words(rp.data_ptr<int>(), N, E, iptr(bp), iptr(ht), &pp, &words), "build_plan(plan size)");
@@ -415,7 +415,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         pybind11::arg("row_pointers"), pybind11::arg("column_index"), pybind11::arg("blockPartition"),
         pybind11::arg("edgeToColumn"), pybind11::arg("hybrid_type"), pybind11::arg("split_threshold") = 0,
         pybind11::arg("segment_len") = 0, pybind11::arg("num_columns") = -1, pybind11::arg("fuse_in_launch") = false,
-        pybind11::arg("slice_threshold") = 0, pybind11::arg("n_slices") = 0);
+        pybind11::arg("slice_threshold") = 0, pybind11::arg("n_slices") = 0, pybind11::arg("panel_cols") = 0);
   m.def("wide_threshold", [](torch::Tensor row_nzr, int embedding_dim, int dtype) {
     hcspmm_plan_header h;
     bool has = false;
@@ -431,17 +431,18 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     TORCH_CHECK(rule >= HCSPMM_RULE_INTENDED && rule <= HCSPMM_RULE_MI355X_WIDE, "unknown rule");
     g_rule = rule;
   }, "0 = intended classifier (default), 1 = with the size>32 guard, 2 = as shipped (hybrid_all_kernel.cu:262), 3 = MI355X refit");
-  m.def("set_plan_params", [](int split_threshold, int segment_len, bool fuse_in_launch, int slice_threshold, int n_slices) {
+  m.def("set_plan_params", [](int split_threshold, int segment_len, bool fuse_in_launch, int slice_threshold, int n_slices, int panel_cols) {
     g_params.split_threshold = split_threshold;
     g_params.segment_len = segment_len;
     g_params.fuse_in_launch = fuse_in_launch ? 1 : 0;
     g_params.slice_threshold = slice_threshold;
     g_params.n_slices = n_slices;
+    g_params.panel_cols = panel_cols;
   }, "rows longer than split_threshold are cut into segments of segment_len entries (0 = defaults); fuse_in_launch: the fused "
      "operators update dense-tile windows inside the hybrid launch; slice_threshold / n_slices: XCD-affine column slices "
      "(hcspmm.h hcspmm_plan_params: 0 = automatic, < 0 = off)",
         pybind11::arg("split_threshold"), pybind11::arg("segment_len"), pybind11::arg("fuse_in_launch") = false,
-        pybind11::arg("slice_threshold") = 0, pybind11::arg("n_slices") = 0);
+        pybind11::arg("slice_threshold") = 0, pybind11::arg("n_slices") = 0, pybind11::arg("panel_cols") = 0);
   m.def("fused_in_launch", [](torch::Tensor row_nzr, int embedding_dim, int hidden_dim) {
     hcspmm_plan_header h;
     if (!row_nzr.defined() || row_nzr.numel() < HCSPMM_PLAN_HEADER_WORDS || row_nzr.scalar_type() != torch::kInt) return false;
@@ -504,7 +505,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     d["uniq_dense"] = h.uniq_dense; d["split_threshold"] = h.split_threshold; d["segment_len"] = h.segment_len;
     d["max_dense_k"] = h.max_dense_k; d["n_tiny"] = h.n_tiny; d["n_dense_compact"] = h.n_dense_compact;
     d["n_dense_compact2"] = h.n_dense_compact2; d["num_columns"] = h.num_columns;
-    d["n_slices"] = h.n_slices; d["slice_threshold"] = h.slice_threshold; d["n_slice_tasks"] = h.n_slice_tasks;
+    d["panel_cols"] = h.panel_cols; d["n_slices"] = h.n_slices; d["slice_threshold"] = h.slice_threshold; d["n_slice_tasks"] = h.n_slice_tasks;
     d["nnz_sliced"] = h.nnz_sliced; d["n_sliced_rows"] = h.n_sliced_rows; d["total_words"] = h.total_words;
     d["n_sparse_windows"] = h.n_sparse_windows; d["dense_k_sum"] = h.dense_k_sum; d["flags"] = h.flags; d["num_nodes"] = h.num_nodes; d["num_edges"] = h.num_edges;
     d["fingerprint"] = ((uint64_t)h.fingerprint_hi << 32) | h.fingerprint_lo;

@@ -161,7 +161,9 @@ typedef struct hcspmm_plan_header {
   int32_t slice_xcd_tasks;  /* max over x in [0, 8) of the descriptors of the slices s = x (mod 8): sizes the region */
   int32_t nnz_sliced;       /* entries covered by sliced tasks (part of nnz_sparse) */
   int32_t n_sliced_rows;
-  int32_t reserved[19];
+  int32_t panel_cols;       /* hcspmm_plan_params.panel_cols: 0 = the launch chooses, > 0: feature columns per
+                               sparse pass for fp32 features (16-bit features: twice as many), < 0: one pass over all columns */
+  int32_t reserved[18];
 } hcspmm_plan_header;
 
 #define HCSPMM_PLAN_FUSE_IN_LAUNCH 1
@@ -178,6 +180,12 @@ typedef struct hcspmm_plan_params {
                               the sparse path holds at least 3 M entries; HCSPMM_SLICE_THRESHOLD in the environment
                               overrides), > 0: rows longer than this are sliced, < 0: off */
   int32_t n_slices;        /* 0 = 8 (HCSPMM_SLICES overrides); rounded up to a multiple of 8, at most 64 */
+  int32_t panel_cols;      /* feature columns per pass of the sparse-row path: 0 = chosen at launch from the plan's counts and
+                              the embedding width (32 fp32 columns = one cache line per gathered row for wide embeddings, 64
+                              when X exceeds the Infinity Cache, one pass for short-row graphs), > 0: this many (a multiple
+                              of 16; fp32 -- 16-bit features take twice as many), < 0: one pass.  The best value depends on
+                              the graph's size and degree mix in no monotone way (profiles/r03/ab_panel_midsize.log): a
+                              caller that will run many steps can measure it (hcspmm.tune_plan in the Python front-end) */
 } hcspmm_plan_params;
 
 /* Number of int32 words a plan for this graph needs (so the caller can allocate the tensor). */

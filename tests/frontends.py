@@ -41,10 +41,10 @@ class CtypesFrontend:
         return self.m.preprocess(col_d, rp_d, N, E, W, rule=rule, num_columns=num_columns)
 
     def build_plan(self, rp_d, col_d, bp, e2c, ht, split_threshold=0, segment_len=0, num_columns=None, fuse_in_launch=False,
-                   slice_threshold=0, n_slices=0):
+                   slice_threshold=0, n_slices=0, panel_cols=0):
         return self.m.build_plan(rp_d, col_d, bp, e2c, ht, split_threshold=split_threshold, segment_len=segment_len,
                                  num_columns=num_columns, fuse_in_launch=fuse_in_launch, slice_threshold=slice_threshold,
-                                 n_slices=n_slices)
+                                 n_slices=n_slices, panel_cols=panel_cols)
 
     def header(self, row_nzr):
         return self.m.plan_header(row_nzr)
@@ -73,10 +73,10 @@ class ExtensionFrontend:
             self.m.set_rule(0)
 
     def build_plan(self, rp_d, col_d, bp, e2c, ht, split_threshold=0, segment_len=0, num_columns=None, fuse_in_launch=False,
-                   slice_threshold=0, n_slices=0):
+                   slice_threshold=0, n_slices=0, panel_cols=0):
         return self.m.build_plan(rp_d, col_d, bp, e2c, ht, int(split_threshold), int(segment_len),
                                  -1 if num_columns is None else int(num_columns), bool(fuse_in_launch), int(slice_threshold),
-                                 int(n_slices))
+                                 int(n_slices), int(panel_cols))
 
     def header(self, row_nzr):
         info = self.m.plan_info(row_nzr)

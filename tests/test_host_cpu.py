@@ -650,3 +650,12 @@ def test_plan_column_slices_automatic_rule():
     rp2, col2 = graphs.uniform_graph(3000, 30000, seed=1)  # no long rows
     bp, e2c, e2r, ht, _, _ = _pre(rp2, col2, 2)
     assert _decode_plan(hcspmm.build_plan(torch.from_numpy(rp2), torch.from_numpy(col2), bp, e2c, ht, num_columns=250000).numpy())[0].n_slices == 0
+
+
+def test_plan_panel_cols_parameter_lands_in_the_header():
+    rp, col = graphs.powerlaw_graph(500, 3000, seed=1)
+    bp, e2c, e2r, ht, _, _ = _pre(rp, col)
+    for asked, stored in ((0, 0), (32, 32), (40, 48), (64, 64), (-3, -1), (-1, -1)):
+        plan = hcspmm.build_plan(torch.from_numpy(rp), torch.from_numpy(col), bp, e2c, ht, panel_cols=asked).numpy()
+        h = _decode_plan(plan)[0]
+        assert h.panel_cols == stored and hcspmm.capi.lib().hcspmm_plan_check(ctypes.byref(h), len(rp) - 1, len(col), len(plan)) == 0

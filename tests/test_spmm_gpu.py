@@ -231,6 +231,37 @@ def test_column_slices_parity(oracle_mod, dev, fe, name, gen, split_free, D, sli
         _check_h16(oracle_mod, g, X16, g.forward(X16))
 
 
+@pytest.mark.parametrize("D", [128, 256, 96])
+@pytest.mark.parametrize("panel_cols", [16, 32, 64, 48, -1, 4096])
+def test_plan_panel_width_parameter(oracle_mod, dev, fe, D, panel_cols):
+    """hcspmm_plan_params.panel_cols: the sparse-row path runs in passes of that many feature columns (any multiple of 16; one
+    pass when it covers the embedding); the result keeps the CSR-order bits whatever the width."""
+    rp, col = graphs.powerlaw_graph(3000, 60000, seed=12, max_degree_frac=0.2)
+    g = Graph(rp, col, dev, fe=fe)
+    g.row_nzr = fe.build_plan(g.rp_d, g.col_d, g.bp, g.e2c, g.ht, panel_cols=panel_cols, slice_threshold=-1)
+    assert g.header().panel_cols == (-1 if panel_cols < 0 else panel_cols)
+    X = np.random.default_rng(D).standard_normal((g.N, D)).astype(np.float32)
+    Z = g.forward(_t(X, dev))
+    _check(oracle_mod, g, X, Z)
+    X16 = _t(X, dev).to(torch.bfloat16)
+    _check_h16(oracle_mod, g, X16, g.forward(X16))
+
+
+def test_tune_plan_returns_the_fastest_measured_variant(oracle_mod, dev):
+    rp, col = graphs.powerlaw_graph(20000, 400000, seed=13)
+    g = Graph(rp, col, dev)
+    plan, report = hcspmm.tune_plan(g.rp_d, g.col_d, g.bp, g.e2c, g.e2r, g.ht, 128, steps=5)
+    assert len(report) >= 4 and report == sorted(report, key=lambda r: r["ms"]) and all(r["ms"] > 0 for r in report)
+    h = hcspmm.plan_header(plan)
+    assert h.panel_cols == report[0]["panel_cols"] and h.num_nodes == g.N
+    g.row_nzr = plan
+    X = np.random.default_rng(1).standard_normal((g.N, 128)).astype(np.float32)
+    _check(oracle_mod, g, X, g.forward(_t(X, dev)))
+    # a caller-chosen candidate list
+    plan2, rep2 = hcspmm.tune_plan(g.rp_d, g.col_d, g.bp, g.e2c, g.e2r, g.ht, 32, candidates=[dict(slice_threshold=8, n_slices=8), dict()], steps=3)
+    assert len(rep2) == 2 and hcspmm.plan_header(plan2).n_slices in (0, 8)
+
+
 @pytest.mark.parametrize("D", [128, 64, 32, 17, 4])
 def test_dense_windows_around_the_compact_record_limit(oracle_mod, dev, fe, D):
     """Dense windows with exactly K = 1 ... 40 (compact 64-word records), 41 ... 80 (128-word records) and 81, 96,

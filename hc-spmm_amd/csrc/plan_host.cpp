@@ -28,7 +28,8 @@
 //             entries; the pieces of slice s go to their own task list, which the kernel serves with workgroups
 //             b = s (mod 8) only.  The L2 of that XCD then sees 1/8 of the columns from those tasks -- on the
 //             Reddit-scale headline a 3.7 MB share of each 30 MB panel of X -- instead of all of them
-//             (tools/l2_hit_simulation.py: 56 % -> 82 % hits at threshold 64).  A column slice of a column-sorted row
+//             (tools/l2_hit_simulation.py: 56 % -> 72 % hits at the default threshold of 256 entries; measured 51 % ->
+//             67 %, the launch 17 % faster and no longer bound by the fabric).  A column slice of a column-sorted row
 //             is a contiguous CSR range, so the pieces are ordinary (row, first, length, slot) tasks whose partial
 //             sums the fix-up pass adds in slice order = CSR order.
 // Blob layout (int32 words): header[64] | tasks[n_tasks][4] | dense_index[n_dense][4] |

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <new>
 #include <vector>
 
@@ -29,6 +30,60 @@ struct hcspmm_dist_ctx {
 };
 
 extern "C" int hcspmm_dist_last_error(void) { return g_last_error; }
+
+// hcspmm/sharded.py partition_rows, restated: cut where (entries + rows before a window boundary) crosses p / world of the total
+extern "C" int hcspmm_dist_partition_rows(const int32_t* rowptr, int64_t N, int world, int64_t* ranges) {
+  if (!rowptr || !ranges || N < 0 || world < 1) return HCSPMM_EINVAL;
+  const int64_t W = (N + HCSPMM_BLK_H - 1) / HCSPMM_BLK_H;
+  auto wstart = [&](int64_t w) { return std::min<int64_t>(w * HCSPMM_BLK_H, N); };
+  auto cost = [&](int64_t w) { return (int64_t)rowptr[wstart(w)] + wstart(w); };
+  const int64_t total = cost(W);
+  int64_t prev = 0;
+  for (int p = 0; p < world; ++p) {
+    int64_t cutw = W;
+    if (p + 1 < world) {
+      // first window boundary whose cost reaches total * (p + 1) / world (compared without rounding: cost * world >= total * (p + 1))
+      int64_t lo = 0, hi = W;
+      while (lo < hi) {
+        const int64_t mid = lo + (hi - lo) / 2;
+        if ((__int128)cost(mid) * world >= (__int128)total * (p + 1)) hi = mid;
+        else lo = mid + 1;
+      }
+      cutw = std::max(prev, std::min(lo, W));
+    }
+    ranges[2 * p] = wstart(prev);
+    ranges[2 * p + 1] = wstart(cutw);
+    prev = cutw;
+  }
+  return HCSPMM_OK;
+}
+
+extern "C" int hcspmm_dist_extract_block(const int32_t* rowptr, const int32_t* col, int64_t N, int world, const int64_t* ranges,
+                                         int rank, int32_t* rp_out, int32_t* col_out, int64_t* pad_rows_out) {
+  if (!rowptr || !ranges || !rp_out || N < 0 || world < 1 || rank < 0 || rank >= world) return HCSPMM_EINVAL;
+  int64_t pad = 0;
+  for (int p = 0; p < world; ++p) {
+    if (ranges[2 * p] < 0 || ranges[2 * p + 1] < ranges[2 * p] || ranges[2 * p + 1] > N) return HCSPMM_EINVAL;
+    if (p > 0 && ranges[2 * p] != ranges[2 * p - 1]) return HCSPMM_EINVAL;
+    pad = std::max(pad, ranges[2 * p + 1] - ranges[2 * p]);
+  }
+  if (ranges[0] != 0 || ranges[2 * world - 1] != N) return HCSPMM_EINVAL;
+  if (pad * world > INT32_MAX) return HCSPMM_ERANGE;
+  const int64_t r0 = ranges[2 * rank], r1 = ranges[2 * rank + 1], e0 = rowptr[r0], e1 = rowptr[r1];
+  if (e1 > e0 && (!col || !col_out)) return HCSPMM_EINVAL;
+  for (int64_t r = r0; r <= r1; ++r) rp_out[r - r0] = (int32_t)(rowptr[r] - e0);
+  std::vector<int64_t> starts((size_t)world);
+  for (int p = 0; p < world; ++p) starts[(size_t)p] = ranges[2 * p];
+  for (int64_t e = e0; e < e1; ++e) {
+    const int64_t v = col[e];
+    if (v < 0 || v >= N) return HCSPMM_EINVAL;
+    // owner: the LAST rank whose first row is <= v (empty blocks share a start with their successor and own nothing)
+    const int64_t owner = (std::upper_bound(starts.begin(), starts.end(), v) - starts.begin()) - 1;
+    col_out[e - e0] = (int32_t)(owner * pad + (v - starts[(size_t)owner]));
+  }
+  if (pad_rows_out) *pad_rows_out = pad;
+  return HCSPMM_OK;
+}
 
 extern "C" int hcspmm_dist_create(int max_panels, hcspmm_dist_ctx** out) {
   if (max_panels <= 0 || max_panels > 4096 || !out) return HCSPMM_EINVAL;

@@ -54,6 +54,20 @@ typedef struct hcspmm_dist_step_args {
   int32_t always_gather;                 /* != 0: take the collective path in a one-rank world as well (tests on a one-GPU box) */
 } hcspmm_dist_step_args;
 
+/* Host side of the shard (no GPU, no communicator needed): which rows a rank owns and what its block looks like.
+ *
+ * hcspmm_dist_partition_rows: contiguous row ranges, boundaries multiples of 16 (a row window is never cut), balanced by
+ * stored entries + rows -- ranges_out[2 * p] = first row of rank p, ranges_out[2 * p + 1] = one past its last.
+ * hcspmm_dist_extract_block: rank's local CSR -- row_pointers_out[n_local + 1] rebased to 0, column_index_out[e_local]
+ * with every global vertex id v replaced by the row of the padded gathered matrix that holds it (owner(v) * pad_rows +
+ * v - first row of owner(v)); pad_rows_out = the common block height max_p(n_local_p).  The block is then preprocessed
+ * with num_columns = world_size * pad_rows (hcspmm_preprocess_host, hcspmm_plan_build).  The caller sizes the outputs:
+ * n_local = ranges[2 * rank + 1] - ranges[2 * rank], e_local = row_pointers[r1] - row_pointers[r0]. */
+int hcspmm_dist_partition_rows(const int32_t* row_pointers_h, int64_t num_nodes, int world_size, int64_t* ranges_out);
+int hcspmm_dist_extract_block(const int32_t* row_pointers_h, const int32_t* column_index_h, int64_t num_nodes, int world_size,
+                              const int64_t* ranges, int rank, int32_t* row_pointers_out, int32_t* column_index_out,
+                              int64_t* pad_rows_out);
+
 /* max_panels events for "gather p has landed" + one for "the compute stream has reached this step". */
 int hcspmm_dist_create(int max_panels, hcspmm_dist_ctx** ctx_out);
 void hcspmm_dist_destroy(hcspmm_dist_ctx* ctx);

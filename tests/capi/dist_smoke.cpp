@@ -81,12 +81,15 @@ static int run_rank(int rank, int world, const char* id_path) {
   const int n_panels = 4, w = (int)D / n_panels;
   std::vector<int32_t> rowptr, col;
   make_graph(N, rowptr, col);
-  // contiguous window-aligned blocks of equal height (the last one shorter): rank p owns rows [p * pad, min(N, (p + 1) * pad))
-  const int64_t pad = ((N + world - 1) / world + 15) / 16 * 16 + 16;  // + 16: every block carries padding rows
-  const int64_t r0 = std::min<int64_t>(N, rank * pad), r1 = std::min<int64_t>(N, (rank + 1) * pad), n_local = r1 - r0;
-  const int64_t M = (int64_t)world * pad;  // rows of the gathered matrix; global vertex v sits at (v / pad) * pad + v % pad = v
-  std::vector<int32_t> rp_l((size_t)n_local + 1), col_l(col.begin() + rowptr[(size_t)r0], col.begin() + rowptr[(size_t)r1]);
-  for (int64_t r = 0; r <= n_local; ++r) rp_l[(size_t)r] = rowptr[(size_t)(r0 + r)] - rowptr[(size_t)r0];
+  // the library's own partition (nnz-balanced, window-aligned: blocks of unequal height, so every rank but the tallest
+  // carries padding rows) and block extraction (column ids remapped to rows of the padded gathered matrix)
+  std::vector<int64_t> ranges((size_t)2 * world);
+  HC_OK(hcspmm_dist_partition_rows(rowptr.data(), N, world, ranges.data()));
+  const int64_t r0 = ranges[(size_t)2 * rank], r1 = ranges[(size_t)2 * rank + 1], n_local = r1 - r0;
+  std::vector<int32_t> rp_l((size_t)n_local + 1), col_l((size_t)(rowptr[(size_t)r1] - rowptr[(size_t)r0]));
+  int64_t pad = 0;
+  HC_OK(hcspmm_dist_extract_block(rowptr.data(), col.data(), N, world, ranges.data(), rank, rp_l.data(), col_l.data(), &pad));
+  const int64_t M = (int64_t)world * pad;  // rows of the gathered matrix: global vertex v sits at owner(v) * pad + (v - first row of owner(v))
   const int64_t E = (int64_t)col_l.size(), W = (n_local + 15) / 16;
   std::vector<int32_t> bp((size_t)W), ht((size_t)W), e2c((size_t)E), e2r((size_t)E);
   HC_OK(hcspmm_preprocess_host(rp_l.data(), col_l.data(), n_local, E, M, HCSPMM_RULE_INTENDED, 2, bp.data(), e2c.data(), e2r.data(), ht.data()));

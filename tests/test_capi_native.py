@@ -33,12 +33,53 @@ def test_dist_library_exports_its_header(tmp_path):
     import re
     header = open(os.path.join(ROOT, "include", "hcspmm_dist.h")).read()
     declared = set(re.findall(r"\b(hcspmm_dist_[a-z_]+)\s*\(", header))
-    assert declared == {"hcspmm_dist_create", "hcspmm_dist_destroy", "hcspmm_dist_step", "hcspmm_dist_last_error"}
+    assert declared == {"hcspmm_dist_create", "hcspmm_dist_destroy", "hcspmm_dist_step", "hcspmm_dist_last_error",
+                        "hcspmm_dist_partition_rows", "hcspmm_dist_extract_block"}
     nm = subprocess.run(["nm", "-D", "--defined-only", os.path.join(CSRC, "libhcspmm_dist.so")], stdout=subprocess.PIPE, text=True).stdout
     assert declared <= set(re.findall(r" T (\w+)", nm))
     needed = subprocess.run(["readelf", "-d", os.path.join(CSRC, "libhcspmm.so")], stdout=subprocess.PIPE, text=True).stdout
     assert "rccl" not in needed and "nccl" not in needed
     assert os.path.exists(_build_dist(tmp_path))
+
+
+def test_dist_host_side_matches_the_python_shard():
+    """hcspmm_dist_partition_rows / _extract_block (C ABI) == hcspmm.sharded.partition_rows / ShardedGraph (what the PyTorch
+    path uses), on graphs with hubs, empty rows and more ranks than row windows."""
+    import ctypes
+    import sys
+    import numpy as np
+    for p in (ROOT, os.path.join(ROOT, "hc-spmm_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from hcspmm import graphs
+    from hcspmm.sharded import ShardedGraph, partition_rows
+    try:
+        L = ctypes.CDLL(os.path.join(CSRC, "libhcspmm_dist.so"))
+    except OSError as e:  # (needs librccl and the HIP runtime to resolve; present in the ROCm image)
+        pytest.skip("libhcspmm_dist.so does not load here: %s" % e)
+    i64, vp = ctypes.c_int64, ctypes.c_void_p
+    L.hcspmm_dist_partition_rows.argtypes = [vp, i64, ctypes.c_int, vp]
+    L.hcspmm_dist_extract_block.argtypes = [vp, vp, i64, ctypes.c_int, vp, ctypes.c_int, vp, vp, ctypes.POINTER(i64)]
+    cases = [graphs.powerlaw_graph(5003, 90000, seed=11, max_degree_frac=0.3), graphs.uniform_graph(1000, 3000, seed=2),
+             graphs.powerlaw_graph(40, 200, seed=3), (np.zeros(101, np.int32), np.zeros(0, np.int32))]
+    for rp, col in cases:
+        N = len(rp) - 1
+        for world in (1, 2, 3, 8):
+            ranges = np.zeros(2 * world, np.int64)
+            assert L.hcspmm_dist_partition_rows(rp.ctypes.data, N, world, ranges.ctypes.data) == 0
+            want = partition_rows(rp, world)
+            assert [tuple(r) for r in ranges.reshape(-1, 2).tolist()] == want
+            for rank in range(world):
+                g = ShardedGraph(rp, col, want, rank)
+                rp_out = np.full(g.n_local + 1, -7, np.int32)
+                col_out = np.full(max(len(g.column_index), 1), -7, np.int32)
+                pad = i64(0)
+                assert L.hcspmm_dist_extract_block(rp.ctypes.data, col.ctypes.data if len(col) else None, N, world, ranges.ctypes.data, rank,
+                                                   rp_out.ctypes.data, col_out.ctypes.data, ctypes.byref(pad)) == 0
+                assert pad.value == g.pad_rows and np.array_equal(rp_out, g.row_pointers)
+                assert np.array_equal(col_out[:len(g.column_index)], g.column_index)
+    bad = np.array([0, 16, 8, 40], np.int64)  # ranges that do not tile the rows
+    assert L.hcspmm_dist_extract_block(cases[2][0].ctypes.data, cases[2][1].ctypes.data, 40, 2, bad.ctypes.data, 0, None, None, None) != 0
 
 
 @pytest.mark.gpu

@@ -43,6 +43,9 @@ def parse_args(argv=None):
     # addition: window classifier (hcspmm.h: 0 the reference's intended rule, 2 as shipped, 3 / 4 the MI355X refits
     # for embedding widths below / from 64)
     p.add_argument("--rule", type=int, default=0, choices=[0, 1, 2, 3, 4], help="window classifier rule")
+    # addition: measure the launch-plan variants no size rule predicts (column slices, panel width) on THIS graph and
+    # GPU and keep the fastest (hcspmm.tune_plan: a few plan builds and a few hundred launches before the first epoch)
+    p.add_argument("--tune", action="store_true", help="tune the launch plan on this graph before training")
     return p.parse_args(argv)
 
 
@@ -95,6 +98,14 @@ def main(argv=None):
         column_index, row_pointers, num_nodes, num_edges, num_row_windows)
     torch.cuda.synchronize()
     print("Prep. (ms):\t{:.3f}".format((time.perf_counter() - start) * 1e3))
+    if args.tune:
+        import hcspmm  # the ctypes front-end of the same library: its plan tensors are what HCSPMM.forward* take as row_nzr
+        start = time.perf_counter()
+        row_nzr, report = hcspmm.tune_plan(row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, hybrid_type,
+                                           args.hidden)
+        print("Tune (ms):\t{:.3f}\tbest {} at {:.4f} ms, automatic plan {:.4f} ms".format(
+            (time.perf_counter() - start) * 1e3, {k: v for k, v in report[0].items() if k != "ms"}, report[0]["ms"],
+            next(r["ms"] for r in report if not r.get("slice_threshold") and not r.get("panel_cols"))))
     graph = (row_pointers, column_index, blockPartition, edgeToColumn, edgeToRow, hybrid_type, row_nzr, col_nzr)
 
     if args.single_kernel:

@@ -164,6 +164,24 @@ def test_driver_end_to_end_on_example_dataset(model, capsys, monkeypatch):
     assert logp.shape == (600, 22) and torch.isfinite(logp).all()
 
 
+@pytest.mark.gpu
+def test_driver_tunes_the_plan_when_asked(capsys, monkeypatch):
+    """--tune (an addition to the reference's flags): hcspmm.tune_plan's plan replaces row_nzr before training; the module
+    `HCSPMM` accepts a plan tensor made by the ctypes front-end of the same library."""
+    _pkg_imports()
+    monkeypatch.chdir(PKG)
+    spec = importlib.util.spec_from_file_location("hc_spmm_main_tune", os.path.join(PKG, "HC-SpMM_main.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    torch.manual_seed(0)
+    net = mod.main(["--dataset", "example", "--dim", "16", "--num_layers", "2", "--hidden", "32", "--classes", "22",
+                    "--epochs", "5", "--model", "gcn", "--tune"])
+    out = capsys.readouterr().out
+    assert "Tune (ms):" in out and "Train (ms/epoch):" in out
+    for name, prm in net.named_parameters():
+        assert prm.grad is not None and torch.isfinite(prm.grad).all(), name
+
+
 def test_reference_style_star_imports_resolve_both_module_names():
     """The reference driver does `import HCSPMM`, `from GNN_model import *`, then calls
     `HYGNN.preprocess(...)` (HC-SpMM_main.py:13-15,52) -- the old module name, never imported there.

@@ -502,6 +502,8 @@ def roofline_of(case, traffic=None, traffic_source=None, l2_request_bytes=None, 
             r["l2"].update({"request_bytes": l2_request_bytes, "gbs": l2_request_bytes / t / 1e9,
                             "frac_of_peak": l2_request_bytes / t / 1e9 / L2_PEAK_GBS})
         if all_hit_ms:
+            if cache_resident and all_hit_ms / case["kernel_ms"] >= 0.7:
+                r["bound"] = "l2 gather rate (X resident in the Infinity Cache; the launch takes < 1.43x its all-hit time)"
             r["l2"].update({"all_hit_kernel_ms": all_hit_ms, "frac_of_all_hit_floor": all_hit_ms / case["kernel_ms"],
                             "all_hit_note": "the same rows and task schedule sizes with every column id folded into [0, 2048) (X = 256 KB per "
                                             "panel: every gather an L2 hit), timed in this run: what the launch would take if nothing missed L2"})

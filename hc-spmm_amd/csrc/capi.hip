@@ -195,6 +195,7 @@ struct FusedOperands {
   long long ldr, ldc;
   float* out;
   int H;
+  int mode;  // bit 0: dense-tile windows update inside the hybrid launch; bit 1: ordinary / tiny sparse rows in the row-tile launch
 };
 
 int forward_impl(const void* X, int64_t x_rows, int64_t ldx, void* Z, int64_t ldz, int dtype, const int32_t* rowptr,
@@ -251,7 +252,7 @@ int forward_impl(const void* X, int64_t x_rows, int64_t ldx, void* Z, int64_t ld
     a.D = D;
     a.sparse_wgs = 0;
     a.n_panels = 0;
-    a.fused = fused ? 1 : 0;
+    a.fused = fused ? fused->mode : 0;
     a.fused_dense_wgs = 0;
     a.H = fused ? fused->H : 0;
     a.W = fused ? fused->W : nullptr;
@@ -259,7 +260,14 @@ int forward_impl(const void* X, int64_t x_rows, int64_t ldx, void* Z, int64_t ld
     a.w_ldc = fused ? fused->ldc : 0;
     a.out = fused ? fused->out : nullptr;
     const int vec = pick_vec(dtype, D, ldx, ldz, X, Z, need ? workspace : nullptr);
-    if (fused && (vec != 4 || dtype != HCSPMM_DTYPE_F32)) return HCSPMM_EINVAL;  // (fused_single_launch_ok said otherwise)
+    if (fused && (vec != 4 || dtype != HCSPMM_DTYPE_F32)) return HCSPMM_EINVAL;  // (fused_form said otherwise)
+    if (fused && (fused->mode & 2)) {
+      // row-tile form: the ordinary / tiny tasks and the dense windows are summed AND multiplied by the tile launches
+      // (fused_rows.hip); the hybrid launch below then runs the sliced and wide tasks only and ends with the fix-up pass,
+      // which also adds the segments of split rows that sit among the ordinary tasks
+      e = hcspmm::launch_fused_tiles(a, stream);
+      if (e != hipSuccess) return fail_hip(e);
+    }
     e = dtype == HCSPMM_DTYPE_F32 ? hcspmm::launch_plan_f32(a, vec, stream)
         : dtype == HCSPMM_DTYPE_F16 ? hcspmm::launch_plan_f16(a, vec, stream)
                                     : hcspmm::launch_plan_bf16(a, vec, stream);
@@ -315,31 +323,41 @@ extern "C" int hcspmm_forward(const float* X, float* Z, const int32_t* rowptr, c
                                 N, E, D, workspace, workspace_bytes, stream_v);
 }
 
-// In-launch form of the fused operators: the dense-tile windows of a planned launch multiply their tile by the
-// weights while it is in the MFMA accumulators (spmm_impl.h fused_dense_region); only the windows on the sparse-row
-// path -- listed in the plan (off_sparse_windows) -- go through the update kernel afterwards.  Taken when the plan
-// asks for it (hcspmm_plan_params.fuse_in_launch; HCSPMM_FUSED_SINGLE_LAUNCH=1 / 0 forces it on / off for every
-// plan), has dense windows and the shape is in range: fp32, D a multiple of 16 from 32 up, H = 16 or 32, W fits the
-// LDS staging area, 16-byte aligned rows.  Not the default: on MI355X it is the slower form (profiles/r02/ab_fused.log).
-static bool fused_single_launch_ok(const hcspmm_plan_header* ph, const void* X, const void* out2, int D, int H,
-                                   const void* workspace = nullptr) {
+// Forms of the fused operators (fp32).  0: two launches -- hybrid SpMM (out2 = A*X), then the streaming update over all rows.
+// 1 ("in-launch", plans built with hcspmm_plan_params.fuse_in_launch = 1): the dense-tile windows multiply their tile by the
+// weights while it is in the MFMA accumulators (spmm_impl.h fused_dense_region); the windows on the sparse-row path -- listed
+// in the plan (off_sparse_windows) -- go through the update kernel afterwards.  2 ("row-tile", fuse_in_launch = 2): the
+// sparse-row path is fused as well -- tiles of 16 consecutive tasks of the length-sorted list are summed, written to out2 and
+// multiplied before they leave the CU (fused_rows.hip); only the rows summed by whole waves or in pieces (wide tasks, split
+// and column-sliced rows: a few thousand) are multiplied by a small launch behind the fix-up pass.  Needs a single column
+// pass (D <= 32, or a short-row graph).  HCSPMM_FUSED_SINGLE_LAUNCH=0 / 1 / 2 forces a form for every plan (falling back
+// when the shape is outside it).  Form 1 alone is the slower form on MI355X (profiles/r02/ab_fused.log); form 2: DESIGN 3.5.
+static int fused_form(const hcspmm_plan_header* ph, const void* X, const void* out2, const void* out, int D, int H,
+                      const void* workspace = nullptr) {
   static const int forced = [] {
     const char* e = getenv("HCSPMM_FUSED_SINGLE_LAUNCH");
-    return !e ? -1 : (e[0] == '0' ? 0 : 1);
+    return !e ? -1 : (e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1));
   }();
-  if (!ph || ph->n_dense <= 0) return false;
-  if (forced == 0 || (forced < 0 && !(ph->flags & HCSPMM_PLAN_FUSE_IN_LAUNCH))) return false;
-  if (D % 16 != 0 || D < 32 || H % 16 != 0 || H > 32 || H <= 0) return false;
-  // the in-launch kernel is the 16-byte-per-lane build: a caller's workspace that is only 4- or 8-byte aligned takes the
-  // two-launch form (which serves every alignment) instead of failing
-  if (!aligned(X, 16) || !aligned(out2, 16) || (workspace && !aligned(workspace, 16))) return false;
-  const int dv = D >= 64 ? 4 : 2;
-  const int rows = (D + 16 * dv - 1) / (16 * dv) * 16 * dv;
-  return (size_t)rows * (size_t)(H + 4) * sizeof(float) <= 64 * 1024;
+  if (!ph) return 0;
+  const int asked = forced >= 0 ? forced : ((ph->flags & HCSPMM_PLAN_FUSE_ROWS) ? 2 : ((ph->flags & HCSPMM_PLAN_FUSE_IN_LAUNCH) ? 1 : 0));
+  if (asked == 0) return 0;
+  // both forms are 16-byte-per-lane builds: a caller's workspace that is only 4- or 8-byte aligned takes the two-launch form
+  // (which serves every alignment) instead of failing
+  if (!aligned(X, 16) || !aligned(out2, 16) || (workspace && !aligned(workspace, 16))) return 0;
+  bool dense_ok = D % 16 == 0 && D >= 32 && H % 16 == 0 && H <= 32 && H > 0;
+  if (dense_ok) {
+    const int dv = D >= 64 ? 4 : 2;
+    const int rows = (D + 16 * dv - 1) / (16 * dv) * 16 * dv;
+    dense_ok = (size_t)rows * (size_t)(H + 4) * sizeof(float) <= 64 * 1024;
+  }
+  if (asked >= 2 && hcspmm::fused_tiles_supported(D, H) && aligned(out, 16) &&
+      panel_choice(ph, D, HCSPMM_DTYPE_F32) >= D)
+    return 2;
+  return (ph->n_dense > 0 && dense_ok) ? 1 : 0;
 }
 
 extern "C" int hcspmm_fused_in_launch(const hcspmm_plan_header* ph, int D, int H) {
-  return fused_single_launch_ok(ph, nullptr, nullptr, D, H) ? 1 : 0;  // (null pointers count as aligned)
+  return fused_form(ph, nullptr, nullptr, nullptr, D, H);  // (null pointers count as aligned)
 }
 
 extern "C" int hcspmm_forward_fused(const float* X, float* out, float* out2, const float* weights, int64_t ldr,
@@ -350,8 +368,21 @@ extern "C" int hcspmm_forward_fused(const float* X, float* out, float* out2, con
                                     size_t workspace_bytes, void* stream_v) {
   if (!out || !out2 || !weights || H <= 0) return HCSPMM_EINVAL;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
-  if (plan_d && ph && fused_single_launch_ok(ph, X, out2, D, H, hcspmm_workspace_bytes(ph, D) ? workspace : nullptr)) {
-    const FusedOperands f{weights, (long long)ldr, (long long)ldc, out, H};
+  const int form = (plan_d && ph) ? fused_form(ph, X, out2, out, D, H, hcspmm_workspace_bytes(ph, D) ? workspace : nullptr) : 0;
+  if (form == 2) {
+    const FusedOperands f{weights, (long long)ldr, (long long)ldc, out, H, 2};
+    const int rc = forward_impl(X, N, D, out2, D, HCSPMM_DTYPE_F32, rowptr, col, blockPartition, edgeToColumn, edgeToRow,
+                                hybrid_type, plan_d, ph, N, E, D, workspace, workspace_bytes, stream_v, &f);
+    if (rc != HCSPMM_OK) return rc;
+    int n_wide = 0;
+    wide_choice(ph, D, HCSPMM_DTYPE_F32, &n_wide);
+    const hipError_t e = hcspmm::launch_dense_update_leftover(out2, weights, (long long)ldr, (long long)ldc, out, (int)N, D, H,
+                                                              plan_d, ph->off_tasks, n_wide, ph->off_fixups, ph->n_split_rows,
+                                                              ph->off_slice_tasks, ph->n_slice_tasks, stream);
+    return e == hipSuccess ? HCSPMM_OK : fail_hip(e);
+  }
+  if (form == 1) {
+    const FusedOperands f{weights, (long long)ldr, (long long)ldc, out, H, 1};
     const int rc = forward_impl(X, N, D, out2, D, HCSPMM_DTYPE_F32, rowptr, col, blockPartition, edgeToColumn, edgeToRow,
                                 hybrid_type, plan_d, ph, N, E, D, workspace, workspace_bytes, stream_v, &f);
     if (rc != HCSPMM_OK) return rc;

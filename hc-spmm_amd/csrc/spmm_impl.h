@@ -978,16 +978,25 @@ static hipError_t launch_plan_LV(const PlanArgs& a, hipStream_t stream) {
   constexpr int R = 64 / L;
   PlanArgs b = a;
   b.n_wide = (R > 1) ? a.n_wide : 0;  // with one lane group per wave a wide task is an ordinary one
+  // a.fused bit 0: dense-tile windows multiply their tile by the weights in this launch (FUSED kernel); bit 1: the ordinary and
+  // tiny tasks of this call run in the row-tile fused launch (fused_rows.hip) -- this launch keeps the sliced region, the
+  // wide tasks and the dense units
+  const bool dense_fused = (a.fused & 1) != 0;
+  if (a.fused & 2) {
+    b.n_tasks = b.n_wide;
+    b.n_tiny = 0;
+    b.n_dense = b.n_dense_compact = b.n_dense_compact2 = 0;  // (dense windows are tiles of that launch as well)
+  }
   b.wide_wgs = (b.n_wide + kWaves - 1) / kWaves;
   // tiny tasks: a region of the hybrid launch, or -- when there are enough of them -- a launch of their own behind it
   static const int tiny_kernel_min = [] {
     const char* e = getenv("HCSPMM_TINY_KERNEL_MIN_TASKS");
     return e ? atoi(e) : HCSPMM_TINY_KERNEL_MIN_TASKS;
   }();
-  const bool own_tiny_launch = !a.fused && tiny_kernel_min >= 0 && a.n_tiny >= tiny_kernel_min && a.n_tiny > 0;
-  b.tiny_kernel_wgs = own_tiny_launch ? (a.n_tiny + kWaves * R * HCSPMM_TINY_KERNEL_T - 1) / (kWaves * R * HCSPMM_TINY_KERNEL_T) : 0;
-  b.tiny_wgs = own_tiny_launch ? 0 : (a.n_tiny + kWaves * R * TinyT<L>::value - 1) / (kWaves * R * TinyT<L>::value);
-  b.free_wgs_pp = b.wide_wgs + (a.n_tasks - a.n_tiny - b.n_wide + kWaves * R - 1) / (kWaves * R) + b.tiny_wgs;
+  const bool own_tiny_launch = !a.fused && tiny_kernel_min >= 0 && b.n_tiny >= tiny_kernel_min && b.n_tiny > 0;
+  b.tiny_kernel_wgs = own_tiny_launch ? (b.n_tiny + kWaves * R * HCSPMM_TINY_KERNEL_T - 1) / (kWaves * R * HCSPMM_TINY_KERNEL_T) : 0;
+  b.tiny_wgs = own_tiny_launch ? 0 : (b.n_tiny + kWaves * R * TinyT<L>::value - 1) / (kWaves * R * TinyT<L>::value);
+  b.free_wgs_pp = b.wide_wgs + (b.n_tasks - b.n_tiny - b.n_wide + kWaves * R - 1) / (kWaves * R) + b.tiny_wgs;
   // the sliced region: per XCD ceil(slice_xcd_tasks / tasks per workgroup) workgroups, interleaved b = x (mod 8); a panel is
   // padded to a multiple of 8 workgroups so that b mod 8 == blockIdx mod 8 in every panel (the idle ones return at once)
   b.slice_wgs = a.n_slices > 0 ? 8 * ((a.slice_xcd_tasks + kWaves * R - 1) / (kWaves * R)) : 0;
@@ -1004,10 +1013,10 @@ static hipError_t launch_plan_LV(const PlanArgs& a, hipStream_t stream) {
   b.n_panels = (a.D + 16 * b.dense_vec - 1) / (16 * b.dense_vec);
   constexpr bool kCanFuse = sizeof(typename E::T) == 4 && VEC == 4;
   constexpr int kMinWaves = sizeof(typename E::T) == 4 ? HCSPMM_MIN_WAVES_PER_SIMD : HCSPMM_MIN_WAVES_H16;
-  if (a.fused && !kCanFuse) return hipErrorInvalidValue;  // the caller checked (capi.hip fused_single_launch_ok)
-  const long long dense_units = (long long)a.n_dense * (a.fused ? 1 : b.n_panels);  // fused: a wave owns a window
+  if (dense_fused && !kCanFuse) return hipErrorInvalidValue;  // the caller checked (capi.hip fused_single_launch_ok)
+  const long long dense_units = (long long)b.n_dense * (dense_fused ? 1 : b.n_panels);  // fused: a wave owns a window
   long long dense_wgs = (dense_units + kWaves - 1) / kWaves;
-  if (a.fused) {
+  if (dense_fused) {
     static const long long cap = [] {
       const char* e = getenv("HCSPMM_FUSED_DENSE_WGS");
       const long long v = e ? atoll(e) : 0;
@@ -1020,7 +1029,7 @@ static hipError_t launch_plan_LV(const PlanArgs& a, hipStream_t stream) {
   if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
   if (grid > 0) {
     if constexpr (kCanFuse) {
-      if (a.fused) {
+      if (dense_fused) {
         const size_t lds = (size_t)b.n_panels * 16 * b.dense_vec * fused_row_stride(a.H, b.dense_vec) * sizeof(float);
         // (four waves per SIMD, like the plain kernel: at three -- 137 registers, nothing spilled -- the in-launch form LOSES 2-10 %: profiles/r02/ab_fused.log)
         hipLaunchKernelGGL((hybrid_plan_kernel<E, L, VEC, HCSPMM_SPARSE_U, HCSPMM_FUSED_MIN_WAVES, true>),

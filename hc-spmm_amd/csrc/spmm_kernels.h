@@ -43,6 +43,13 @@ struct PlanArgs {
   float* out;
 };
 
+// Arguments of the row-tile fused launch (fused_rows.hip): the planned launch's arguments (Z = out2; W / out / H set) plus the
+// tile counts.  fp32, 16 bytes per lane.
+struct TilesArgs {
+  PlanArgs p;
+  int n_ord_tiles, n_tiny_tiles;  // filled by the launcher: tiles of 16 ordinary / tiny tasks
+};
+
 // Arguments of the plan-free launch: the reference's seven graph tensors as they are.
 struct WindowArgs {
   const void* X;
@@ -78,6 +85,18 @@ hipError_t launch_weight_grad(const float* A, long long lda, const float* B, lon
 // nullptr = every tile.
 hipError_t launch_dense_update(const float* in, const float* W, long long ldr, long long ldc, float* out, int N,
                                int D, int H, const int* tile_list, int n_tiles, hipStream_t stream);
+// Row-tile form of the fused operators (fused_rows.hip): persistent launches that sum 16 tasks (or one dense window) at a
+// time, write out2 and multiply the tile by the weights before it leaves the CU.  a: as for launch_plan_f32 with vec = 4
+// (n_wide / panel_cols from wide_choice; needs panel_cols >= D); the hybrid launch with a.fused = 2 (sliced and wide tasks
+// only + fix-up pass) follows.  fused_tiles_supported: the (D, H) shapes.
+bool fused_tiles_supported(int D, int H);
+hipError_t launch_fused_tiles(const PlanArgs& a, hipStream_t stream);
+// out rows of the sparse-path rows that launch does not cover -- whole rows among the n_wide longest tasks, split rows
+// (fix-up list), column-sliced rows that fell into one piece -- read from `in` (= out2, after the fix-up pass).
+// Shapes: dense_update_streams(in, out, D, H).
+hipError_t launch_dense_update_leftover(const float* in, const float* W, long long ldr, long long ldc, float* out, int N,
+                                        int D, int H, const int* plan, int off_tasks, int n_wide, int off_fixups,
+                                        int n_split_rows, int off_slice_tasks, int n_slice_tasks, hipStream_t stream);
 // true when launch_dense_update takes the LDS-staged streaming kernel for this shape (the shapes the single-launch
 // fused dense-tile epilogue is built for as well)
 bool dense_update_streams(const float* in, const float* out, int D, int H);

@@ -134,6 +134,97 @@ __global__ __launch_bounds__(kUpdWaves * 64) void dense_update_stream_kernel(con
   }
 }
 
+// The same product for a scattered set of rows: the sparse-path rows the row-tile fused launch (fused_rows.hip) leaves out.
+// Item j of the list is one of the n_wide longest tasks (a whole row when its slot is < 0), a fix-up entry (a split or
+// column-sliced row, complete after the fix-up pass) or a slice descriptor (a sliced row that fell into ONE piece keeps a
+// direct store: row >= 0 and slot < 0); everything else in those lists is skipped.  16 items per wave step; lane i reads
+// row(item i), the store addresses of rows 4*kq + r come from that lane by shuffle.  Same k order as above => same bits.
+template <int T>
+__global__ __launch_bounds__(kUpdWaves * 64) void dense_update_rows_kernel(const float* __restrict__ in,
+                                                                           const float* __restrict__ W, long long ldr,
+                                                                           long long ldc, float* __restrict__ out, int D,
+                                                                           const int* __restrict__ plan, int off_tasks,
+                                                                           int n_wide, int off_fixups, int n_split_rows,
+                                                                           int off_slice_tasks, int n_slice_tasks) {
+  extern __shared__ __attribute__((aligned(16))) float s_w[];
+  constexpr int H = 16 * T;
+  constexpr int HS = H + 4;
+  for (int i = threadIdx.x; i < D * H; i += kUpdWaves * 64) {
+    const int k = i / H, h = i - k * H;
+    s_w[k * HS + h] = W[(long long)k * ldr + (long long)h * ldc];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int n_items = n_wide + n_split_rows + n_slice_tasks;
+  const int n_tiles = (n_items + 15) / 16;
+  const int4* tasks = reinterpret_cast<const int4*>(plan + off_tasks);
+  const int4* fixups = reinterpret_cast<const int4*>(plan + off_fixups);
+  const int4* slices = reinterpret_cast<const int4*>(plan + off_slice_tasks);
+  for (int ti = (int)blockIdx.x * kUpdWaves + wave; ti < n_tiles; ti += (int)gridDim.x * kUpdWaves) {
+    const int j = ti * 16 + i;
+    int row = -1;
+    if (j < n_wide) {
+      const int4 t = tasks[j];
+      row = t.w < 0 ? t.x : -1;
+    } else if (j < n_wide + n_split_rows) {
+      row = fixups[j - n_wide].x;
+    } else if (j < n_items) {
+      const int4 t = slices[j - n_wide - n_split_rows];
+      row = (t.x >= 0 && t.w < 0) ? t.x : -1;
+    }
+    if (__builtin_amdgcn_ballot_w64(row >= 0) == 0) continue;  // wave-uniform
+    const bool rok = row >= 0;
+    const f32x4* arow = reinterpret_cast<const f32x4*>(in + (size_t)(rok ? row : 0) * (size_t)D) + kq;
+    f32x4 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < D; k0 += 64) {
+      f32x4 a[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (rok && k0 + 16 * u < D) a[u] = arow[(k0 >> 2) + 4 * u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (k0 + 16 * u < D) {
+          const float* wrow = s_w + (k0 + 16 * u + 4 * kq) * HS + T * i;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+              acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][q], wrow[q * HS + t], acc[t], 0, 0, 0);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int orow = __shfl(row, 4 * kq + r, 64);
+      if (orow >= 0) {
+        float* o = out + (size_t)orow * (size_t)H + T * i;
+#pragma unroll
+        for (int t = 0; t < T; ++t) o[t] = acc[t][r];
+      }
+    }
+  }
+}
+
+template <int T>
+static hipError_t launch_rows(const float* in, const float* W, long long ldr, long long ldc, float* out, int D,
+                              const int* plan, int off_tasks, int n_wide, int off_fixups, int n_split_rows,
+                              int off_slice_tasks, int n_slice_tasks, hipStream_t stream) {
+  const size_t lds = (size_t)D * (16 * T + 4) * sizeof(float);
+  const long long n_tiles = ((long long)n_wide + n_split_rows + n_slice_tasks + 15) / 16;
+  int grid = (int)((n_tiles + kUpdWaves - 1) / kUpdWaves);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL((dense_update_rows_kernel<T>), dim3(grid), dim3(kUpdWaves * 64), lds, stream, in, W, ldr, ldc, out, D,
+                     plan, off_tasks, n_wide, off_fixups, n_split_rows, off_slice_tasks, n_slice_tasks);
+  return hipGetLastError();
+}
+
 template <int T>
 static hipError_t launch_stream(const float* in, const float* W, long long ldr, long long ldc, float* out, int N, int D,
                                 const int* tile_list, int n_tiles, hipStream_t stream) {
@@ -312,6 +403,17 @@ hipError_t launch_dense_update(const float* in, const float* W, long long ldr, l
   hipLaunchKernelGGL(dense_update_kernel, dim3(grid), dim3(kUpdWaves * 64), 0, stream, in, W, ldr, ldc, out, N, D, H,
                      tile_list, n_tiles);
   return hipGetLastError();
+}
+
+hipError_t launch_dense_update_leftover(const float* in, const float* W, long long ldr, long long ldc, float* out, int N,
+                                        int D, int H, const int* plan, int off_tasks, int n_wide, int off_fixups,
+                                        int n_split_rows, int off_slice_tasks, int n_slice_tasks, hipStream_t stream) {
+  if (N <= 0 || (long long)n_wide + n_split_rows + n_slice_tasks <= 0) return hipSuccess;
+  if (!dense_update_streams(in, out, D, H) || H > 32) return hipErrorInvalidValue;
+  return H == 32 ? launch_rows<2>(in, W, ldr, ldc, out, D, plan, off_tasks, n_wide, off_fixups, n_split_rows, off_slice_tasks,
+                                  n_slice_tasks, stream)
+                 : launch_rows<1>(in, W, ldr, ldc, out, D, plan, off_tasks, n_wide, off_fixups, n_split_rows, off_slice_tasks,
+                                  n_slice_tasks, stream);
 }
 
 }  // namespace hcspmm

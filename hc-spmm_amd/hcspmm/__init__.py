@@ -152,10 +152,10 @@ def workspace_bytes(row_nzr, embedding_dim):
 
 
 def fused_in_launch(row_nzr, embedding_dim, hidden_dim):
-    """True when forward_*_fused with this plan and shape updates its dense-tile windows inside the hybrid launch
-    (hcspmm_fused_in_launch, include/hcspmm.h)."""
+    """Form forward_*_fused takes with this plan and shape (hcspmm_fused_in_launch, include/hcspmm.h): 0 = two launches,
+    1 = dense-tile windows update inside the hybrid launch, 2 = the sparse-row path as well (row-tile form)."""
     h = plan_header(row_nzr)
-    return bool(h is not None and lib().hcspmm_fused_in_launch(ctypes.byref(h), int(embedding_dim), int(hidden_dim)))
+    return int(lib().hcspmm_fused_in_launch(ctypes.byref(h), int(embedding_dim), int(hidden_dim))) if h is not None else 0
 
 
 def _ptr(t):
@@ -257,15 +257,16 @@ def build_plan(row_pointers, column_index, blockPartition, edgeToColumn, hybrid_
                split_threshold=0, segment_len=0, num_columns=None, fuse_in_launch=False, slice_threshold=0, n_slices=0,
                panel_cols=0):
     """Launch plan for an arbitrary window classification (e.g. every window forced onto one sub-path,
-    or a classifier of the caller's own): -> plan tensor to pass as `row_nzr`.  fuse_in_launch: the fused
-    operators update this plan's dense-tile windows inside the hybrid launch (include/hcspmm.h hcspmm_forward_fused).
+    or a classifier of the caller's own): -> plan tensor to pass as `row_nzr`.  fuse_in_launch: 1 (or True) = the fused
+    operators update this plan's dense-tile windows inside the hybrid launch, 2 = the sparse-row path as well (row-tile
+    form; include/hcspmm.h hcspmm_forward_fused).
     slice_threshold / n_slices: XCD-affine column slices (hcspmm_plan_params; 0 = automatic, < 0 = off).
     panel_cols: feature columns per pass of the sparse-row path (0 = chosen at launch, < 0 = one pass; see tune_plan)."""
     L = lib()
     rp_h, col_h = _i32_host(row_pointers), _i32_host(column_index)
     bp_h, e2c_h, ht_h = _i32_host(blockPartition), _i32_host(edgeToColumn), _i32_host(hybrid_type)
     N, E = rp_h.numel() - 1, col_h.numel()
-    params = PlanParams(int(split_threshold), int(segment_len), int(bool(fuse_in_launch)), int(slice_threshold), int(n_slices),
+    params = PlanParams(int(split_threshold), int(segment_len), int(fuse_in_launch), int(slice_threshold), int(n_slices),
                         int(panel_cols)) \
         if (split_threshold or segment_len or fuse_in_launch or slice_threshold or n_slices or panel_cols) else _PLAN_PARAMS
     words = ctypes.c_int64(0)

@@ -359,12 +359,12 @@ torch::Tensor spmm_forward_into(torch::Tensor input, torch::Tensor output, torch
 // build_plan: launch plan for an arbitrary window classification (e.g. every window forced onto one sub-path)
 torch::Tensor build_plan(torch::Tensor row_pointers, torch::Tensor column_index, torch::Tensor blockPartition,
                          torch::Tensor edgeToColumn, torch::Tensor hybrid_type, int split_threshold, int segment_len,
-                         int64_t num_columns, bool fuse_in_launch, int slice_threshold, int n_slices, int panel_cols) {
+                         int64_t num_columns, int fuse_in_launch, int slice_threshold, int n_slices, int panel_cols) {
   auto rp = to_host_i32(row_pointers), col = to_host_i32(column_index), bp = to_host_i32(blockPartition),
        e2c = to_host_i32(edgeToColumn), ht = to_host_i32(hybrid_type);
   const int64_t N = rp.numel() - 1, E = col.numel();
   hcspmm_plan_params pp = (split_threshold || segment_len || fuse_in_launch || slice_threshold || n_slices || panel_cols)
-                              ? hcspmm_plan_params{split_threshold, segment_len, fuse_in_launch ? 1 : 0, slice_threshold, n_slices, panel_cols}
+                              ? hcspmm_plan_params{split_threshold, segment_len, fuse_in_launch, slice_threshold, n_slices, panel_cols}
                               : g_params;
   int64_t words = 0;
   check_rc(hcspmm_plan_words(rp.data_ptr<int>(), N, E, iptr(bp), iptr(ht), &pp, &words), "build_plan(plan size)");
@@ -414,7 +414,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("build_plan", &build_plan, "launch plan (row_nzr) for a caller-supplied window classification",
         pybind11::arg("row_pointers"), pybind11::arg("column_index"), pybind11::arg("blockPartition"),
         pybind11::arg("edgeToColumn"), pybind11::arg("hybrid_type"), pybind11::arg("split_threshold") = 0,
-        pybind11::arg("segment_len") = 0, pybind11::arg("num_columns") = -1, pybind11::arg("fuse_in_launch") = false,
+        pybind11::arg("segment_len") = 0, pybind11::arg("num_columns") = -1, pybind11::arg("fuse_in_launch") = 0,
         pybind11::arg("slice_threshold") = 0, pybind11::arg("n_slices") = 0, pybind11::arg("panel_cols") = 0);
   m.def("wide_threshold", [](torch::Tensor row_nzr, int embedding_dim, int dtype) {
     hcspmm_plan_header h;
@@ -431,25 +431,26 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     TORCH_CHECK(rule >= HCSPMM_RULE_INTENDED && rule <= HCSPMM_RULE_MI355X_WIDE, "unknown rule");
     g_rule = rule;
   }, "0 = intended classifier (default), 1 = with the size>32 guard, 2 = as shipped (hybrid_all_kernel.cu:262), 3 = MI355X refit");
-  m.def("set_plan_params", [](int split_threshold, int segment_len, bool fuse_in_launch, int slice_threshold, int n_slices, int panel_cols) {
+  m.def("set_plan_params", [](int split_threshold, int segment_len, int fuse_in_launch, int slice_threshold, int n_slices, int panel_cols) {
     g_params.split_threshold = split_threshold;
     g_params.segment_len = segment_len;
-    g_params.fuse_in_launch = fuse_in_launch ? 1 : 0;
+    g_params.fuse_in_launch = fuse_in_launch;
     g_params.slice_threshold = slice_threshold;
     g_params.n_slices = n_slices;
     g_params.panel_cols = panel_cols;
-  }, "rows longer than split_threshold are cut into segments of segment_len entries (0 = defaults); fuse_in_launch: the fused "
-     "operators update dense-tile windows inside the hybrid launch; slice_threshold / n_slices: XCD-affine column slices "
+  }, "rows longer than split_threshold are cut into segments of segment_len entries (0 = defaults); fuse_in_launch: 1 = the fused "
+     "operators update dense-tile windows inside the hybrid launch, 2 = sparse rows as well (row-tile form); slice_threshold / n_slices: XCD-affine column slices "
      "(hcspmm.h hcspmm_plan_params: 0 = automatic, < 0 = off)",
-        pybind11::arg("split_threshold"), pybind11::arg("segment_len"), pybind11::arg("fuse_in_launch") = false,
+        pybind11::arg("split_threshold"), pybind11::arg("segment_len"), pybind11::arg("fuse_in_launch") = 0,
         pybind11::arg("slice_threshold") = 0, pybind11::arg("n_slices") = 0, pybind11::arg("panel_cols") = 0);
   m.def("fused_in_launch", [](torch::Tensor row_nzr, int embedding_dim, int hidden_dim) {
     hcspmm_plan_header h;
-    if (!row_nzr.defined() || row_nzr.numel() < HCSPMM_PLAN_HEADER_WORDS || row_nzr.scalar_type() != torch::kInt) return false;
+    if (!row_nzr.defined() || row_nzr.numel() < HCSPMM_PLAN_HEADER_WORDS || row_nzr.scalar_type() != torch::kInt) return 0;
     auto host = row_nzr.slice(0, 0, HCSPMM_PLAN_HEADER_WORDS).cpu().contiguous();
     std::memcpy(&h, host.data_ptr<int>(), sizeof(h));
-    return h.magic == HCSPMM_PLAN_MAGIC && hcspmm_fused_in_launch(&h, embedding_dim, hidden_dim) != 0;
-  }, "true when forward_*_fused with this plan and shape updates its dense-tile windows inside the hybrid launch");
+    return h.magic == HCSPMM_PLAN_MAGIC ? hcspmm_fused_in_launch(&h, embedding_dim, hidden_dim) : 0;
+  }, "form forward_*_fused takes with this plan and shape: 0 = two launches, 1 = dense-tile windows update inside the hybrid "
+     "launch, 2 = the sparse-row path as well (row-tile form)");
   m.def("abi_version", []() { return hcspmm_abi_version(); });
   // LOI layout reorder on the host (the reference ships it as a separate file-to-file program, LOI.cpp)
   m.def("loi_reorder", [](torch::Tensor row_pointers, torch::Tensor column_index, int variant) {

@@ -167,6 +167,7 @@ typedef struct hcspmm_plan_header {
 } hcspmm_plan_header;
 
 #define HCSPMM_PLAN_FUSE_IN_LAUNCH 1
+#define HCSPMM_PLAN_FUSE_ROWS 2 /* ... and the sparse-row path as well: the row-tile form (hcspmm_plan_params.fuse_in_launch = 2) */
 
 /* Tunables for the plan; zero-initialise for defaults. */
 typedef struct hcspmm_plan_params {

@@ -75,7 +75,7 @@ class ExtensionFrontend:
     def build_plan(self, rp_d, col_d, bp, e2c, ht, split_threshold=0, segment_len=0, num_columns=None, fuse_in_launch=False,
                    slice_threshold=0, n_slices=0, panel_cols=0):
         return self.m.build_plan(rp_d, col_d, bp, e2c, ht, int(split_threshold), int(segment_len),
-                                 -1 if num_columns is None else int(num_columns), bool(fuse_in_launch), int(slice_threshold),
+                                 -1 if num_columns is None else int(num_columns), int(fuse_in_launch), int(slice_threshold),
                                  int(n_slices), int(panel_cols))
 
     def header(self, row_nzr):

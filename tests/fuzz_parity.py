@@ -80,11 +80,13 @@ def main():
         X = rng.standard_normal((N, D)).astype(np.float32)
         strided = mode != "plan_free" and rng.random() < 0.3  # X and Z as column slices of wider matrices
         fused = dtype == torch.float32 and mode != "plan_free" and not strided and rng.random() < 0.35
-        in_launch = fused and rng.random() < 0.6
-        if in_launch:  # the same classification, plan flagged so that dense windows update inside the hybrid launch
-            g.row_nzr = fe.build_plan(g.rp_d, g.col_d, g.bp, g.e2c, g.ht, fuse_in_launch=True, **slice_kw)
+        in_launch = int(rng.choice([0, 1, 2, 2])) if fused else 0
+        if in_launch:  # the same classification, plan flagged so that dense windows (1) / every tile (2: row-tile form; one column
+            # pass forced half of the time so that wide embeddings take it too) are multiplied inside the aggregation launches
+            g.row_nzr = fe.build_plan(g.rp_d, g.col_d, g.bp, g.e2c, g.ht, fuse_in_launch=in_launch,
+                                      panel_cols=-1 if (in_launch == 2 and rng.random() < 0.5) else 0, **slice_kw)
         tag = "%s/%s%s%s/%s" % (mode, str(dtype).replace("torch.", ""), "/strided" if strided else "",
-                                ("/fused_in_launch" if in_launch else "/fused") if fused else "", fe.name)
+                                ("/fused_form%d" % in_launch) if fused else "", fe.name)
 
         def run(Xd):
             if not strided:
@@ -98,7 +100,7 @@ def main():
             return wide_z[:, offz:offz + D].contiguous()
         try:
             if fused:
-                H = int(rng.choice([16, 32, 32, 7, 64, 48]))
+                H = int(rng.choice([16, 32, 32, 32, 7, 64, 48]))
                 Wm = rng.standard_normal((D, H)).astype(np.float32)
                 Xd, Wd = torch.from_numpy(X).to(dev), torch.from_numpy(Wm).to(dev)
                 out, out2 = fe.forward_fixed32_fused(Xd, *g.args(), Wd)

@@ -37,8 +37,8 @@ def _resource_usage(unit):
 def usage():
     """Both translation units, compiled side by side (the 16-bit one takes about a minute)."""
     from concurrent.futures import ThreadPoolExecutor
-    units = ("spmm_kernels.hip", "spmm_kernels_h16.hip")
-    with ThreadPoolExecutor(2) as ex:
+    units = ("spmm_kernels.hip", "spmm_kernels_h16.hip", "fused_rows.hip")
+    with ThreadPoolExecutor(3) as ex:
         return dict(zip(units, ex.map(_resource_usage, units)))
 
 
@@ -84,3 +84,15 @@ def test_16bit_planned_kernels_keep_four_waves_and_do_not_spill(usage):
         # (the 64-lanes-per-task builds -- 16-bit rows wider than 256 / 512 columns in one pass -- carry one 20-byte reload since
         # the argument block grew in round 3; every build a panel-major launch uses is spill-free)
         assert u["occupancy"] >= 4 and u["scratch"] <= (24 if a[1] == 64 else 0), (a, u)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
+def test_fused_tile_kernels_do_not_spill(usage):
+    """Row-tile form of the fused operators (fused_rows.hip): the sparse-row tiles are built for five waves per SIMD, the
+    dense-window tiles for four; neither spills (a one-launch build of both spilled 140 bytes per lane and lost 25 %)."""
+    usage = usage["fused_rows.hip"]
+    tiles = {n: u for n, u in usage.items() if "fused_tiles_kernel" in n}
+    assert len(tiles) == 16  # (L, DV) in {(8, 2), (16, 2), (16, 4), (32, 4)} x H in {16, 32} x {sparse, dense}
+    for n, u in tiles.items():
+        kind = int(re.search(r"ELi(\d+)EEEvNS_9TilesArgsE", n).group(1))
+        assert u["scratch"] == 0 and u["occupancy"] >= (5 if kind == 1 else 4), (n, u)

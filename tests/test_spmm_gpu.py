@@ -415,6 +415,7 @@ _FUSED_GRAPHS = [
     ("powerlaw", lambda: graphs.powerlaw_graph(1200, 9000, seed=6)),
     ("planted_ragged", lambda: graphs.planted_dense_graph(1500 - 7, seed=14)),  # compact dense windows, N % 16 != 0
     ("wide_windows", lambda: _wide_window_graph()),                             # K = 48..130: double records + regular packs
+    ("hubs", lambda: graphs.powerlaw_graph(3000, 30000, seed=9, max_degree_frac=0.3)),  # hub rows: wide / split / sliced
 ]
 
 
@@ -436,23 +437,38 @@ def _wide_window_graph(seed=11):
 @pytest.mark.parametrize("D,H", [(32, 32), (64, 64), (96, 22), (32, 7), (16, 40), (128, 32), (48, 16), (256, 32), (16, 16),
                                  (96, 16), (128, 64), (64, 32), (32, 16), (512, 32)])
 @pytest.mark.parametrize("gname,gen", _FUSED_GRAPHS, ids=[g[0] for g in _FUSED_GRAPHS])
-@pytest.mark.parametrize("form", ["two_launches", "in_launch"])
+@pytest.mark.parametrize("form", ["two_launches", "in_launch", "row_tiles"])
 def test_fused_variants(oracle_mod, dev, fe, gname, gen, D, H, form):
-    """out2 = A*X, out = out2 * W for every fused name of the reference's module, in both forms of the operator: the
-    default (hybrid launch + update launch) and, for plans built with fuse_in_launch, dense-tile windows updated inside
-    the hybrid launch (transposed-tile MFMA chain) where the shape allows; the wide_windows graph is forced all-dense so
-    that every record kind takes that path."""
+    """out2 = A*X, out = out2 * W for every fused name of the reference's module, in the three forms of the operator: the
+    default (hybrid launch + update launch); for plans built with fuse_in_launch = 1, dense-tile windows updated inside
+    the hybrid launch (transposed-tile MFMA chain) where the shape allows; for fuse_in_launch = 2 the sparse-row path as
+    well (tiles of 16 tasks summed, parked in LDS and multiplied in one launch -- `out` must have the two-launch form's
+    BITS).  The wide_windows graph is forced all-dense so that every record kind takes the in-launch path; the hubs graph
+    is forced all-sparse with small split / slice thresholds so that the rows the row-tile launch leaves out (whole-wave
+    rows, split rows, sliced rows in one piece) go through the leftover update."""
     rp, col = gen()
-    g = Graph(rp, col, dev, fe=fe, force_type=1 if gname == "wide_windows" else None)
+    g = Graph(rp, col, dev, fe=fe, force_type={"wide_windows": 1, "hubs": 0}.get(gname))
     assert not hcspmm.fused_in_launch(g.row_nzr, 32, 32)  # the default plan: two launches
-    if form == "in_launch":
-        g.row_nzr = fe.build_plan(g.rp_d, g.col_d, g.bp, g.e2c, g.ht, fuse_in_launch=True)
-    in_launch = hcspmm.fused_in_launch(g.row_nzr, D, H)
+    kw = dict(split_threshold=48, segment_len=16, slice_threshold=20) if gname == "hubs" else {}
+    if kw:
+        g.row_nzr = fe.build_plan(g.rp_d, g.col_d, g.bp, g.e2c, g.ht, **kw)
+        assert g.header().n_split_rows > 0 and g.header().n_slices > 0
+    Xr = torch.randn(g.N, D, device=dev)
+    Wr = torch.randn(D, H, device=dev)
+    out_two = fe.forward_fixed32_fused(Xr, *g.args(), Wr)[0]  # the two-launch form on the same task cut
+    asked = {"two_launches": 0, "in_launch": 1, "row_tiles": 2}[form]
+    if asked:  # (row tiles need the sparse region in one column pass: automatic below 64 columns and on short-row graphs)
+        g.row_nzr = fe.build_plan(g.rp_d, g.col_d, g.bp, g.e2c, g.ht, fuse_in_launch=asked, panel_cols=-1 if asked == 2 else 0, **kw)
+    h = g.header()
     # in the launch: asked for, fp32, D a multiple of 16 from 32 up, H = 16 or 32 (output tiles held in registers), W fits the LDS staging area
-    assert in_launch == (form == "in_launch" and g.header().n_dense > 0 and D % 16 == 0 and D >= 32 and H in (16, 32)
-                         and D * (H + 4) * 4 <= 64 * 1024)
-    if gname != "powerlaw":
-        assert g.header().n_dense > 0
+    dense_ok = D % 16 == 0 and D >= 32 and H in (16, 32) and D * (H + 4) * 4 <= 64 * 1024
+    rows_ok = D % 16 == 0 and 32 <= D <= 128 and H in (16, 32)
+    assert hcspmm.fused_in_launch(g.row_nzr, D, H) == (2 if asked == 2 and rows_ok else (1 if asked and h.n_dense > 0 and dense_ok else 0))
+    if gname not in ("powerlaw", "hubs"):
+        assert h.n_dense > 0
+    if asked == 2:  # rows of the sparse-row path: the update is the streaming kernel's MFMA chain, fed from LDS instead of HBM
+        sparse_rows = torch.repeat_interleave(g.ht == 0, 16)[:g.N]
+        assert torch.equal(fe.forward_fixed32_fused(Xr, *g.args(), Wr)[0][sparse_rows], out_two[sparse_rows])
     rng = np.random.default_rng(7)
     X = rng.standard_normal((g.N, D)).astype(np.float32)
     W = rng.standard_normal((D, H)).astype(np.float32)

@@ -1,8 +1,10 @@
 """A/B of the fused aggregate+update operators (reference hybrid_all_kernel.cu:1639-1848 etc.):
   two-launch form  : hybrid SpMM launch (writes out2 = A*X) + streaming MFMA update launch over ALL rows;
   in-launch form   : dense-tile windows multiply their tile by W inside the hybrid launch (tile kept in the MFMA
-                     accumulators), update launch restricted to the sparse-row windows.
-Each form runs in its own process (HCSPMM_FUSED_SINGLE_LAUNCH = 0 / 1 forces the form for every plan; read once).
+                     accumulators), update launch restricted to the sparse-row windows;
+  row-tile form    : the sparse-row path as well -- tiles of 16 tasks summed, parked in LDS and multiplied in one launch
+                     (fused_rows.hip), a small update launch for the rows summed by whole waves or in pieces.
+Each form runs in its own process (HCSPMM_FUSED_SINGLE_LAUNCH = 0 / 1 / 2 forces the form for every plan; read once).
 
   python tools/ab_fused.py            -> prints one table; the builder keeps it as profiles/r02/ab_fused.log
 """
@@ -16,6 +18,8 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "hc-spmm_amd")]
 
 WORKLOADS = ["dense", "yh_like", "c5_share", "alldense", "reddit"]
 SHAPES = [(32, 32), (128, 32), (64, 64)]
+if os.environ.get("AB_SHAPES"):  # e.g. AB_SHAPES=32x32,128x32
+    SHAPES = [tuple(int(v) for v in sh.split("x")) for sh in os.environ["AB_SHAPES"].split(",")]
 
 
 def child():
@@ -64,7 +68,7 @@ def child():
 def main():
     wls = sys.argv[1] if len(sys.argv) > 1 else ",".join(WORKLOADS)
     res = {}
-    for mode in ("0", "1"):
+    for mode in ("0", "1", "2"):
         env = dict(os.environ, HCSPMM_FUSED_SINGLE_LAUNCH=mode)
         p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", wls], env=env, stdout=subprocess.PIPE,
                            stderr=subprocess.PIPE, text=True)
@@ -74,13 +78,15 @@ def main():
             sys.exit(1)
         res[mode] = json.loads(line[0][7:])
     print("fused aggregate+update, one MI355X; times in us per call (50 calls after 5 warm-ups, HIP events)")
-    print("%-26s %9s %9s | %12s %12s %8s | %s" % ("workload / shape", "dense win", "sparse win", "two launches", "in-launch", "gain",
-                                                 "SpMM alone"))
+    print("forms: two launches | dense windows in the hybrid launch (1) | sparse rows as well: row tiles (2); (n) = form actually taken")
+    print("%-26s %9s %9s | %12s %16s %16s | %s" % ("workload / shape", "dense win", "sparse win", "two launches", "in-launch", "row tiles",
+                                                   "SpMM alone"))
     for k in res["0"]:
-        a, b = res["0"][k], res["1"][k]
-        print("%-26s %9d %9d | %12.1f %12.1f %7.1f%% | %10.1f   %s" % (k, a["dense_windows"], a["sparse_windows"], a["fused_us"],
-                                                                      b["fused_us"], 100.0 * (a["fused_us"] - b["fused_us"]) / a["fused_us"],
-                                                                      a["spmm_us"], "" if b["in_launch"] else "(shape/plan outside the in-launch form)"))
+        a, b, c = res["0"][k], res["1"][k], res["2"][k]
+        gain = lambda x: 100.0 * (a["fused_us"] - x["fused_us"]) / a["fused_us"]
+        print("%-26s %9d %9d | %12.1f %8.1f %+5.1f%% (%d) %8.1f %+5.1f%% (%d) | %10.1f" % (
+            k, a["dense_windows"], a["sparse_windows"], a["fused_us"], b["fused_us"], gain(b), int(b["in_launch"]), c["fused_us"], gain(c),
+            int(c["in_launch"]), a["spmm_us"]))
 
 
 if __name__ == "__main__":

@@ -326,12 +326,17 @@ extern "C" int hcspmm_forward(const float* X, float* Z, const int32_t* rowptr, c
 // Forms of the fused operators (fp32).  0: two launches -- hybrid SpMM (out2 = A*X), then the streaming update over all rows.
 // 1 ("in-launch", plans built with hcspmm_plan_params.fuse_in_launch = 1): the dense-tile windows multiply their tile by the
 // weights while it is in the MFMA accumulators (spmm_impl.h fused_dense_region); the windows on the sparse-row path -- listed
-// in the plan (off_sparse_windows) -- go through the update kernel afterwards.  2 ("row-tile", fuse_in_launch = 2): the
-// sparse-row path is fused as well -- tiles of 16 consecutive tasks of the length-sorted list are summed, written to out2 and
-// multiplied before they leave the CU (fused_rows.hip); only the rows summed by whole waves or in pieces (wide tasks, split
-// and column-sliced rows: a few thousand) are multiplied by a small launch behind the fix-up pass.  Needs a single column
-// pass (D <= 32, or a short-row graph).  HCSPMM_FUSED_SINGLE_LAUNCH=0 / 1 / 2 forces a form for every plan (falling back
-// when the shape is outside it).  Form 1 alone is the slower form on MI355X (profiles/r02/ab_fused.log); form 2: DESIGN 3.5.
+// in the plan (off_sparse_windows) -- go through the update kernel afterwards.  Slower than 0 on MI355X (profiles/r02/ab_fused.log).
+// 2 ("row-tile", fused_rows.hip): tiles of 16 consecutive tasks of the length-sorted list, and dense windows, are summed,
+// written to out2, parked in LDS and multiplied before they leave the CU; the hybrid launch keeps the sliced and wide tasks,
+// whose rows (a few thousand) a small launch multiplies behind the fix-up pass.  `out` has form 0's bits.  Needs the sparse
+// region in ONE column pass (D < 64, or a short-row graph), 32 <= D <= 128, D % 16 == 0, H = 16 or 32.
+// Which one: HCSPMM_FUSED_SINGLE_LAUNCH=0 / 1 / 2 in the environment, else the plan's flags (fuse_in_launch = -1 / 1 / 2),
+// else automatic: form 2 for graphs of at least a million rows at D <= 64 -- out2 is then far beyond what the update launch
+// finds in the caches, and not re-reading it is worth +8 ... +34 % (profiles/r03/ab_fused_rows.log: TT / RD / YeastH-sized
+// low-degree graphs, the dense-heavy 1-2 M-node graphs); at Reddit scale (233 K rows, out2 = 30 MB, cache-resident) it is
+// 1-2 % slower than two launches, and beyond 64 columns the tiles' LDS area caps the occupancy (-3 ... +12 %), so those stay
+// opt-in.  A shape outside a form falls back to the next one down.
 static int fused_form(const hcspmm_plan_header* ph, const void* X, const void* out2, const void* out, int D, int H,
                       const void* workspace = nullptr) {
   static const int forced = [] {
@@ -339,21 +344,26 @@ static int fused_form(const hcspmm_plan_header* ph, const void* X, const void* o
     return !e ? -1 : (e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1));
   }();
   if (!ph) return 0;
-  const int asked = forced >= 0 ? forced : ((ph->flags & HCSPMM_PLAN_FUSE_ROWS) ? 2 : ((ph->flags & HCSPMM_PLAN_FUSE_IN_LAUNCH) ? 1 : 0));
+  int asked = forced;
+  if (asked < 0) {
+    if (ph->flags & HCSPMM_PLAN_FUSE_NEVER) asked = 0;
+    else if (ph->flags & HCSPMM_PLAN_FUSE_ROWS) asked = 2;
+    else if (ph->flags & HCSPMM_PLAN_FUSE_IN_LAUNCH) asked = 1;
+    else asked = (ph->num_nodes >= 1000000 && D <= 64) ? 2 : 0;
+  }
   if (asked == 0) return 0;
   // both forms are 16-byte-per-lane builds: a caller's workspace that is only 4- or 8-byte aligned takes the two-launch form
   // (which serves every alignment) instead of failing
   if (!aligned(X, 16) || !aligned(out2, 16) || (workspace && !aligned(workspace, 16))) return 0;
-  bool dense_ok = D % 16 == 0 && D >= 32 && H % 16 == 0 && H <= 32 && H > 0;
+  if (asked >= 2 && hcspmm::fused_tiles_supported(D, H) && aligned(out, 16) && panel_choice(ph, D, HCSPMM_DTYPE_F32) >= D) return 2;
+  if (!(ph->flags & HCSPMM_PLAN_FUSE_IN_LAUNCH) && forced != 1) return 0;  // form 1 only where it was asked for by name
+  bool dense_ok = ph->n_dense > 0 && D % 16 == 0 && D >= 32 && H % 16 == 0 && H <= 32 && H > 0;
   if (dense_ok) {
     const int dv = D >= 64 ? 4 : 2;
     const int rows = (D + 16 * dv - 1) / (16 * dv) * 16 * dv;
     dense_ok = (size_t)rows * (size_t)(H + 4) * sizeof(float) <= 64 * 1024;
   }
-  if (asked >= 2 && hcspmm::fused_tiles_supported(D, H) && aligned(out, 16) &&
-      panel_choice(ph, D, HCSPMM_DTYPE_F32) >= D)
-    return 2;
-  return (ph->n_dense > 0 && dense_ok) ? 1 : 0;
+  return dense_ok ? 1 : 0;
 }
 
 extern "C" int hcspmm_fused_in_launch(const hcspmm_plan_header* ph, int D, int H) {

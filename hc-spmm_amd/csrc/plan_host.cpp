@@ -74,7 +74,7 @@ Resolved resolve(const hcspmm_plan_params* p) {
   if (p) {
     if (p->split_threshold > 0) r.split_threshold = p->split_threshold;
     if (p->segment_len > 0) r.segment_len = p->segment_len;
-    r.fuse_in_launch = p->fuse_in_launch < 0 ? 0 : (p->fuse_in_launch > 2 ? 2 : p->fuse_in_launch);
+    r.fuse_in_launch = p->fuse_in_launch < 0 ? -1 : (p->fuse_in_launch > 2 ? 2 : p->fuse_in_launch);
   }
   if (r.segment_len > r.split_threshold) r.segment_len = r.split_threshold;
   int thr = p ? p->slice_threshold : 0, ns = p ? p->n_slices : 0;
@@ -626,7 +626,7 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
   h.fingerprint_lo = (uint32_t)(fingerprint & 0xffffffffull);
   h.fingerprint_hi = (uint32_t)(fingerprint >> 32);
   h.dense_k_sum = (int32_t)std::min<int64_t>(L.dense_k_sum, INT32_MAX);
-  h.flags = (rp.fuse_in_launch >= 1 ? HCSPMM_PLAN_FUSE_IN_LAUNCH : 0) | (rp.fuse_in_launch >= 2 ? HCSPMM_PLAN_FUSE_ROWS : 0);
+  h.flags = rp.fuse_in_launch < 0 ? HCSPMM_PLAN_FUSE_NEVER : (rp.fuse_in_launch >= 2 ? HCSPMM_PLAN_FUSE_ROWS : (rp.fuse_in_launch == 1 ? HCSPMM_PLAN_FUSE_IN_LAUNCH : 0));
   h.n_slices = S;
   h.slice_threshold = slicing ? rp.slice_threshold : 0;
   h.off_slice_table = (int32_t)L.off_slice_table;

@@ -127,8 +127,17 @@ __global__ __launch_bounds__(kUpdWaves * 64) void dense_update_stream_kernel(con
       const int orow = r0 + 4 * kq + r;
       if (orow < N) {
         float* o = out + (size_t)orow * (size_t)H + T * i;
+        // written once, not read by this operator: non-temporal stores (1-4 % on the two-launch form, 9 % on the all-dense
+        // graph at D = 32: profiles/r03/ab_fused_rows.log)
+        if constexpr (T == 2) {
+          typedef float f32x2 __attribute__((ext_vector_type(2)));
+          __builtin_nontemporal_store(f32x2{acc[0][r], acc[1][r]}, reinterpret_cast<f32x2*>(o));
+        } else if constexpr (T == 4) {
+          __builtin_nontemporal_store(f32x4{acc[0][r], acc[1][r], acc[2][r], acc[3][r]}, reinterpret_cast<f32x4*>(o));
+        } else {
 #pragma unroll
-        for (int t = 0; t < T; ++t) o[t] = acc[t][r];
+          for (int t = 0; t < T; ++t) __builtin_nontemporal_store(acc[t][r], o + t);
+        }
       }
     }
   }

@@ -168,14 +168,16 @@ typedef struct hcspmm_plan_header {
 
 #define HCSPMM_PLAN_FUSE_IN_LAUNCH 1
 #define HCSPMM_PLAN_FUSE_ROWS 2 /* ... and the sparse-row path as well: the row-tile form (hcspmm_plan_params.fuse_in_launch = 2) */
+#define HCSPMM_PLAN_FUSE_NEVER 4 /* always two launches (fuse_in_launch < 0); no flag = the operator chooses per call */
 
 /* Tunables for the plan; zero-initialise for defaults. */
 typedef struct hcspmm_plan_params {
   int32_t split_threshold; /* default 512 */
   int32_t segment_len;     /* default 256 */
-  int32_t fuse_in_launch;  /* != 0: hcspmm_forward_fused multiplies the dense-tile windows by the weights inside the
-                              hybrid launch (see there).  Default 0: measured on MI355X the two-launch form is 0-8 % faster
-                              (profiles/r02/ab_fused.log) */
+  int32_t fuse_in_launch;  /* form of hcspmm_forward_fused for this plan (see there): 0 = chosen per call (row tiles for graphs
+                              of a million rows and more at D <= 64, else two launches), < 0 = always two launches, 1 = dense-tile
+                              windows multiply by the weights inside the hybrid launch (slower on MI355X:
+                              profiles/r02/ab_fused.log), 2 = row tiles wherever the shape allows */
   int32_t slice_threshold; /* XCD-affine column slices: 0 = automatic (on for num_columns >= 65536 when at least 5 % of
                               the sparse-path entries sit in rows longer than 256 entries and -- below 250 000 columns --
                               the sparse path holds at least 3 M entries; HCSPMM_SLICE_THRESHOLD in the environment
@@ -299,20 +301,24 @@ int32_t hcspmm_wide_threshold_typed(const hcspmm_plan_header* header_h, int embe
  * (bindings B.cpp:310-498) and their kernels K.cu:1639-2770.
  * `out_d` may be a caller-owned buffer (forward_final_fused writes the caller's `output`).
  *
- * Two forms.  Default: the hybrid launch (out2 = A * X) followed by one streaming MFMA update launch over all rows.
- * In-launch form, for a plan built with hcspmm_plan_params.fuse_in_launch (or HCSPMM_FUSED_SINGLE_LAUNCH=1 in the
- * environment) that has dense-tile windows, fp32, D a multiple of 16 from 32 up, H = 16 or 32: those windows are updated
- * INSIDE the hybrid launch: the aggregation runs with exchanged MFMA operands, which leaves each lane holding one
- * row of the 16 x D tile in exactly the A-operand shape of the (tile x weights) MFMAs, so the tile goes from the
- * accumulators straight into the update (W staged in LDS) without touching LDS or HBM -- the reference keeps it in
- * shared memory (K.cu:1807-1837).  The windows on the sparse-row path, whose rows are spread over unrelated waves
- * by the length-sorted task schedule, are then multiplied by a second launch restricted to them (the plan lists
- * them: off_sparse_windows).  The in-launch kernel needs 128 registers (four waves per SIMD against the plain
- * kernel's five) and puts ~100 MFMAs per window on the critical path of latency-bound waves, which on this chip costs
- * more than re-reading out2 from the Infinity Cache saves: it is the slower form here, kept for the record and for
- * chips where the balance differs (A/B: profiles/r02/ab_fused.log).
- * hcspmm_fused_in_launch() tells which form a (plan, D, H) gets (1 = dense windows update in the hybrid launch);
- * HCSPMM_FUSED_SINGLE_LAUNCH=0 / 1 in the environment forces the two-launch / in-launch form for every plan.
+ * Three forms, the same results (out2 bit-identical in all of them; out bit-identical in forms 0 and 2).
+ * 0, two launches: the hybrid launch (out2 = A * X) followed by one streaming MFMA update launch over all rows.
+ * 2, row tiles (fused_rows.hip; the reference keeps a window's aggregate in shared memory and multiplies it in the same
+ *   block, K.cu:1807-1837): persistent launches take 16 CONSECUTIVE TASKS of the length-sorted task list (the update does
+ *   not care which 16 rows share a tile), or one dense-tile window, sum them exactly as the plain kernel does, write the
+ *   rows of out2 from the registers, park the 16 x D tile in a wave-private LDS area and run the update's MFMA chain on
+ *   it (weights staged in LDS once per workgroup), so out2 is never read back.  Rows summed by whole waves or in pieces
+ *   (wide tasks, split and column-sliced rows) stay in the hybrid launch and are multiplied by a small launch behind the
+ *   fix-up pass.  fp32, D a multiple of 16 in [32, 128], H = 16 or 32, sparse region in one column pass (D < 64, or a
+ *   short-row graph, or hcspmm_plan_params.panel_cols < 0).  +8 ... +34 % over form 0 on graphs of a million rows and
+ *   more at D <= 64 (profiles/r03/ab_fused_rows.log) -- chosen automatically there; opt-in elsewhere.
+ * 1, in-launch (round 2; plans built with fuse_in_launch = 1, dense-tile windows only): the aggregation runs with
+ *   exchanged MFMA operands, which leaves each lane holding one row of the 16 x D tile in the A-operand shape of the
+ *   (tile x weights) MFMAs, so the tile goes from the accumulators straight into the update; windows on the sparse-row
+ *   path are multiplied by a second launch restricted to them (off_sparse_windows).  128 registers, ~100 MFMAs on the
+ *   critical path of latency-bound waves: 0-15 % slower than form 0 here (profiles/r02/ab_fused.log); kept for the record.
+ * hcspmm_fused_in_launch() tells which form a (plan, D, H) gets; HCSPMM_FUSED_SINGLE_LAUNCH=0 / 1 / 2 in the environment
+ * forces a form for every plan (shapes outside it fall back).
  * ---------------------------------------------------------------------------------------- */
 int hcspmm_fused_in_launch(const hcspmm_plan_header* header_h, int embedding_dim, int hidden_dim);
 int hcspmm_forward_fused(const float* X_d, float* out_d, float* out2_d, const float* weights_d,

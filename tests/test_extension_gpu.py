@@ -205,3 +205,12 @@ def test_extension_plan_params_select_the_in_launch_fused_form(HCSPMM, oracle_mo
         assert np.all(np.abs(o.cpu().numpy().astype(np.float64) - want_out) <= 1e-5 * scale + 1e-30)
     outs3 = HCSPMM.preprocess(col_d, rp_d, N, len(col), (N + 15) // 16)
     assert HCSPMM.plan_info(outs3[4])["flags"] == 0
+    # fuse_in_launch = 2: the row-tile form (sparse rows as well); `out` then has the two-launch form's bits
+    HCSPMM.set_plan_params(0, 0, 2, 0, 0, -1)
+    try:
+        outs4 = HCSPMM.preprocess(col_d, rp_d, N, len(col), (N + 15) // 16)
+    finally:
+        HCSPMM.set_plan_params(0, 0)
+    assert HCSPMM.plan_info(outs4[4])["flags"] == 2 and HCSPMM.fused_in_launch(outs4[4], 64, 32) == 2
+    out, out2 = HCSPMM.forward_fixed32_fused(Xd, rp_d, col_d, *outs4, Wd)
+    assert torch.equal(out2, ref_out2) and torch.equal(out, ref_out)

@@ -463,12 +463,11 @@ def test_fused_variants(oracle_mod, dev, fe, gname, gen, D, H, form):
     # in the launch: asked for, fp32, D a multiple of 16 from 32 up, H = 16 or 32 (output tiles held in registers), W fits the LDS staging area
     dense_ok = D % 16 == 0 and D >= 32 and H in (16, 32) and D * (H + 4) * 4 <= 64 * 1024
     rows_ok = D % 16 == 0 and 32 <= D <= 128 and H in (16, 32)
-    assert hcspmm.fused_in_launch(g.row_nzr, D, H) == (2 if asked == 2 and rows_ok else (1 if asked and h.n_dense > 0 and dense_ok else 0))
+    assert hcspmm.fused_in_launch(g.row_nzr, D, H) == (2 if asked == 2 and rows_ok else (1 if asked == 1 and h.n_dense > 0 and dense_ok else 0))
     if gname not in ("powerlaw", "hubs"):
         assert h.n_dense > 0
-    if asked == 2:  # rows of the sparse-row path: the update is the streaming kernel's MFMA chain, fed from LDS instead of HBM
-        sparse_rows = torch.repeat_interleave(g.ht == 0, 16)[:g.N]
-        assert torch.equal(fe.forward_fixed32_fused(Xr, *g.args(), Wr)[0][sparse_rows], out_two[sparse_rows])
+    if asked == 2:  # the update is the streaming kernel's MFMA chain, fed from LDS instead of HBM: the two-launch form's bits
+        assert torch.equal(fe.forward_fixed32_fused(Xr, *g.args(), Wr)[0], out_two)
     rng = np.random.default_rng(7)
     X = rng.standard_normal((g.N, D)).astype(np.float32)
     W = rng.standard_normal((D, H)).astype(np.float32)
@@ -499,6 +498,58 @@ def test_fused_variants(oracle_mod, dev, fe, gname, gen, D, H, form):
     out, out2 = fe.forward_fixed32_fused(_t(Xi, dev), *g.args(), _t(Wi, dev))
     zi = oracle_mod.spmm_f32(rp, col, Xi)
     assert np.array_equal(out2.cpu().numpy(), zi) and np.array_equal(out.cpu().numpy(), zi.astype(np.float64) @ Wi.astype(np.float64))
+
+
+@pytest.mark.parametrize("D,H", [(32, 32), (64, 16)])
+def test_fused_row_tiles_are_automatic_on_million_row_graphs(oracle_mod, dev, fe, D, H):
+    """A graph of a million rows and more takes the row-tile form without being asked (out2 is far beyond what the update
+    launch finds in the caches); a plan built with fuse_in_launch = -1 keeps two launches.  Same bits in out2 AND out; exact
+    integer checksums over every row of both sub-paths; sampled rows against the oracle.  (Composite graph: compact dense
+    windows, tiny / ordinary / wide / split / column-sliced rows.)"""
+    rp, col = graphs.planted_dense_graph_fast(1100000, seed=5, dense_fraction=0.4, k_cols=12, fill=0.5, sparse_degree=3)
+    N = len(rp) - 1
+    rng = np.random.default_rng(5)
+    rows = np.repeat(np.arange(N, dtype=np.int64), np.diff(rp))
+    hub_r = np.repeat(np.array([17, 300011, 1099990, 555555]), [700, 1300, 520, 12000])
+    picks = rng.choice(N, 6000, replace=False)
+    long_r = np.repeat(picks[:3000], 300)  # rows beyond the slice threshold, holding a third of the sparse entries: slices on
+    mid_r = np.repeat(picks[3000:], 40)    # ordinary tasks of several length classes
+    extra_r = np.concatenate([hub_r, long_r, mid_r])
+    rp, col = graphs._to_csr(np.concatenate([rows, extra_r]),
+                             np.concatenate([col.astype(np.int64), rng.integers(0, N, extra_r.shape[0])]), N)
+    g = Graph(rp, col, dev, fe=fe)
+    h = g.header()
+    assert h.n_dense > 0 and h.n_tiny > 0 and h.n_split_rows > 0 and h.n_slices > 0 and h.n_tasks > h.n_tiny
+    assert hcspmm.fused_in_launch(g.row_nzr, D, H) == 2
+    never = fe.build_plan(g.rp_d, g.col_d, g.bp, g.e2c, g.ht, fuse_in_launch=-1)
+    assert hcspmm.fused_in_launch(never, D, H) == 0
+    X = torch.randn(N, D, device=dev)
+    W = torch.randn(D, H, device=dev)
+    out, out2 = fe.forward_fixed32_fused(X, *g.args(), W)
+    args0 = g.args()[:6] + (never, g.col_nzr)
+    out_0, out2_0 = fe.forward_fixed32_fused(X, *args0, W)
+    assert torch.equal(out2, out2_0) and torch.equal(out, out_0)
+    assert torch.equal(out2, g.forward(X))
+    assert torch.equal(out, fe.forward_fixed32_fused(X, *g.args(), W)[0])  # deterministic
+    # integer-valued X and W: exact
+    ids = (np.arange(N) % 7).astype(np.float32)  # (every partial sum of out stays below 2^24: 12 000 x 8 x 2 D)
+    Xi = np.tile(ids[:, None], (1, D)) + (np.arange(D, dtype=np.float32) % 3)[None, :]
+    Wi = ((np.arange(D)[:, None] + 2 * np.arange(H)[None, :]) % 5 - 2).astype(np.float32)
+    oi, o2i = fe.forward_fixed32_fused(_t(Xi, dev), *g.args(), _t(Wi, dev))
+    cs = np.concatenate([[0.0], np.cumsum(ids[col].astype(np.float64))])
+    deg = np.diff(rp).astype(np.float64)
+    want2 = (cs[rp[1:]] - cs[rp[:-1]])[:, None] + deg[:, None] * (np.arange(D) % 3)[None, :]
+    assert np.array_equal(o2i.cpu().numpy(), want2.astype(np.float32))
+    assert np.array_equal(oi.cpu().numpy(), (want2 @ Wi.astype(np.float64)).astype(np.float32))
+    # sampled rows vs the oracle
+    rs = np.concatenate([rng.choice(N, 2000, replace=False), [17, 300011, 555555]])
+    sub_rp = np.concatenate([[0], np.cumsum(np.diff(rp)[rs])]).astype(np.int32)
+    sub_col = np.concatenate([col[rp[r]:rp[r + 1]] for r in rs]).astype(np.int32)
+    Xh, Wh = X.cpu().numpy(), W.cpu().numpy()
+    assert oracle_mod.check_spmm(out2.cpu().numpy()[rs], sub_rp, sub_col, Xh)[0]
+    want_out, _ = oracle_mod.spmm_fused_f32(sub_rp, sub_col, Xh, Wh)
+    scale = oracle_mod.spmm_f64(sub_rp, sub_col, Xh, absolute=True) @ np.abs(Wh).astype(np.float64)
+    assert np.all(np.abs(out.cpu().numpy()[rs].astype(np.float64) - want_out) <= 1e-5 * scale + 1e-30)
 
 
 @pytest.mark.parametrize("N,D,H", [(70001, 96, 32), (5000, 32, 32), (9999, 32, 22), (4097, 64, 64), (300, 7, 3),

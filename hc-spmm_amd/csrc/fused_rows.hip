@@ -20,6 +20,8 @@
 // dense_update_rows_kernel multiplies those rows behind the fix-up pass.
 // Applies when the sparse region is ONE column pass (D <= 32, or short-row graphs at any D <= 128): a panel-major
 // launch (Reddit-scale, D >= 64) never has a whole row in one wave, and there re-reading out2 costs 5 % of the step.
+#include <mutex>
+
 #include "spmm_impl.h"
 
 namespace hcspmm {
@@ -307,14 +309,28 @@ bool fused_tiles_supported(int D, int H) {
   return D % 16 == 0 && D >= 32 && D <= 128 && (H == 16 || H == 32) && fused_tiles_lds_bytes(D, H) <= 64 * 1024;
 }
 
-// workgroups the chip holds at once (persistent launch: more than that would queue behind whole strided loops)
+// workgroups the chip holds at once (persistent launch: more than that would queue behind whole strided loops).  Asked once per
+// kernel and LDS size (the occupancy query costs tens of microseconds on the host: not per launch).
 template <int L, int HT, int DV, int KIND>
 static long long resident_wgs(size_t lds) {
+  static std::mutex mu;
+  static size_t seen_lds[4] = {0, 0, 0, 0};
+  static long long seen_wgs[4] = {0, 0, 0, 0};
+  std::lock_guard<std::mutex> lock(mu);
+  for (int i = 0; i < 4; ++i)
+    if (seen_wgs[i] > 0 && seen_lds[i] == lds) return seen_wgs[i];
   int per_cu = 0, cus = 0, dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return 1024;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_tiles_kernel<L, HT, DV, KIND>, kThreads, lds) != hipSuccess || per_cu <= 0) per_cu = 4;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-  return (long long)per_cu * cus;
+  const long long wgs = (long long)per_cu * cus;
+  for (int i = 0; i < 4; ++i)
+    if (seen_wgs[i] == 0) {
+      seen_lds[i] = lds;
+      seen_wgs[i] = wgs;
+      break;
+    }
+  return wgs;
 }
 
 template <int L, int HT, int DV, int KIND>

@@ -17,8 +17,12 @@ class Data:
     pass
 
 
-def build(n, e, dim, classes, seed):
-    rp, col = graphs.powerlaw_graph(n, e, seed=seed)
+def build(n, e, dim, classes, seed, workload=None):
+    if workload:  # one of bench.py's graphs (the paper's Table-II-sized low-degree shapes)
+        import bench
+        rp, col = bench.make_local_block(workload, n, e, 1, 0)
+    else:
+        rp, col = graphs.powerlaw_graph(n, e, seed=seed)
     d = Data()
     d.num_nodes, d.num_features, d.num_classes = n, dim, classes
     d.row_pointers, d.column_index = torch.from_numpy(rp).to(dev), torch.from_numpy(col).to(dev)
@@ -43,8 +47,14 @@ class Net(nn.Module):
         return F.log_softmax(self.conv2(x, *self.graph, self.output), dim=1)
 
 
-for name, n, e in (("cora-scale", 10000, 50000), ("reddit-scale", 233000, 11600000)):
-    d = build(n, e, 96, 22, 1 if n == 10000 else 3)
+# usage: gnn_epoch_timing.py [rd_like|yh_like|tt_like]   (default: Cora- and Reddit-scale); HCSPMM_FUSED_SINGLE_LAUNCH=0 in the
+# environment gives the two-launch form of the fused operators for an A/B of the million-row graphs
+CASES = (("cora-scale", 10000, 50000, None), ("reddit-scale", 233000, 11600000, None))
+if len(sys.argv) > 1:
+    import bench
+    CASES = tuple((w + " (bench.py workload)", bench.WORKLOADS[w][0], bench.WORKLOADS[w][1], w) for w in sys.argv[1:])
+for name, n, e, wl in CASES:
+    d = build(n, e, 96, 22, 1 if n == 10000 else 3, wl)
     t0 = time.perf_counter()
     outs = HCSPMM.preprocess(d.column_index, d.row_pointers, n, d.column_index.numel(), (n + 15) // 16)
     torch.cuda.synchronize()

@@ -798,6 +798,8 @@ def main():
         torch.cuda.empty_cache()
         if sweep_plan:
             out["sweep"] = sweep(fe, dev, args, sweep_plan, graph_of, pmc)
+        if sweep_plan and any(w == "rd_like" for w, _ in sweep_plan):
+            out["fused"] = fused_block(dev, graph_of)
         if world == 1 and not args.no_cpu_baseline and not strong:
             Xh = torch.randn(case["x_rows"], D, generator=torch.Generator().manual_seed(1234)).numpy()
             out["cpu_baseline"] = cpu_baseline(rp, col, Xh, D, case["x_rows"])
@@ -807,6 +809,54 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def fused_block(dev, graph_of, wl="rd_like", D=32, H=32, steps=30):
+    """The fused aggregate+update operator (the GCN-backward shape) on the RD-sized low-degree graph of the sweep:
+    two launches (a plan built with fuse_in_launch = -1) against the row-tile form the operator picks by itself from a million
+    rows on -- HIP events around `steps` calls each, same graph, same tensors, out compared bit for bit.
+    Not part of `value`; never takes the headline down."""
+    import torch
+    import hcspmm
+    try:
+        rp, col = graph_of(wl)
+        N, E = len(rp) - 1, len(col)
+        rp_d, col_d = torch.from_numpy(rp).to(dev), torch.from_numpy(col).to(dev)
+        outs = hcspmm.preprocess(col_d, rp_d, N, E, (N + 15) // 16)
+        never = hcspmm.build_plan(rp_d, col_d, outs[0], outs[1], outs[3], fuse_in_launch=-1)
+        X, W = torch.randn(N, D, device=dev), torch.randn(D, H, device=dev)
+
+        def timed(fn):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(steps):
+                fn()
+            e.record()
+            torch.cuda.synchronize()
+            return s.elapsed_time(e) / steps
+        a_auto = (rp_d, col_d, *outs)
+        a_two = (rp_d, col_d, outs[0], outs[1], outs[2], outs[3], never, outs[5])
+        form = int(hcspmm.fused_in_launch(outs[4], D, H))
+        t_two = timed(lambda: hcspmm.forward_fixed32_fused(X, *a_two, W))
+        t_auto = timed(lambda: hcspmm.forward_fixed32_fused(X, *a_auto, W))
+        t_spmm = timed(lambda: hcspmm.forward(X, *a_auto))
+        o_two, o_auto = hcspmm.forward_fixed32_fused(X, *a_two, W), hcspmm.forward_fixed32_fused(X, *a_auto, W)
+        same = bool(torch.equal(o_two[0], o_auto[0]) and torch.equal(o_two[1], o_auto[1]))
+        h = hcspmm.plan_header(outs[4])
+        res = {"operator": "forward_fixed32_fused: out2 = A*X, out = out2*W", "workload": wl, "nodes": N, "entries": E, "dim": D, "hidden": H,
+               "dense_windows": h.n_dense, "sparse_tasks": h.n_tasks, "two_launches_ms": t_two, "chosen_form": form,
+               "chosen_form_ms": t_auto, "gain_percent": 100.0 * (t_two - t_auto) / t_two, "spmm_alone_ms": t_spmm,
+               "out_and_out2_bit_identical_between_forms": same, "steps": steps,
+               "note": "form 2 = 16-row tiles of both sub-paths summed, parked in LDS and multiplied by W before they leave the CU "
+                       "(csrc/fused_rows.hip); chosen automatically from a million rows on at dim <= 64"}
+        del outs, never, X, W, o_two, o_auto
+        torch.cuda.empty_cache()
+        return res
+    except Exception as ex:
+        return {"error": str(ex)[:300]}
 
 
 def sweep(fe, dev, args, plan, graph_of, pmc):

@@ -246,7 +246,9 @@ __device__ __forceinline__ void tile_update(const float* __restrict__ tile, cons
     if (orow >= 0) {
       float* o = out + (size_t)orow * (size_t)H + HT * i;
       // `out` is written once and not read by this operator: non-temporal stores (+4 ... +9 % on the whole call)
-      if constexpr (HT == 2) {
+      if constexpr (HT == 4) {
+        __builtin_nontemporal_store(f32x4{oacc[0][r], oacc[1][r], oacc[2][r], oacc[3][r]}, reinterpret_cast<f32x4*>(o));
+      } else if constexpr (HT == 2) {
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         __builtin_nontemporal_store(f32x2{oacc[0][r], oacc[1][r]}, reinterpret_cast<f32x2*>(o));
       } else {
@@ -304,9 +306,9 @@ size_t fused_tiles_lds_bytes(int D, int H) {
   return ((size_t)D * rows_w_stride(H) + (size_t)kWaves * (16 * rows_tile_stride(D) + 16)) * sizeof(float);
 }
 
-// shapes the row-tile form serves: fp32 rows of 16-byte pieces, one lane group of at most 32 lanes per row, H = 16 or 32
+// shapes the row-tile form serves: fp32 rows of 16-byte pieces, one lane group of at most 32 lanes per row, H = 16, 32 or 64
 bool fused_tiles_supported(int D, int H) {
-  return D % 16 == 0 && D >= 32 && D <= 128 && (H == 16 || H == 32) && fused_tiles_lds_bytes(D, H) <= 64 * 1024;
+  return D % 16 == 0 && D >= 32 && D <= 128 && (H == 16 || H == 32 || H == 64) && fused_tiles_lds_bytes(D, H) <= 64 * 1024;
 }
 
 // workgroups the chip holds at once (persistent launch: more than that would queue behind whole strided loops).  Asked once per
@@ -357,11 +359,21 @@ static hipError_t launch_tiles_LHD(TilesArgs ta, hipStream_t stream) {
   return hipGetLastError();
 }
 
+template <int L, int DV, int KIND>
+static hipError_t launch_tiles_LDK(const TilesArgs& ta, hipStream_t stream) {
+  switch (ta.p.H) {
+    case 16: return launch_tiles_LHD<L, 1, DV, KIND>(ta, stream);
+    case 32: return launch_tiles_LHD<L, 2, DV, KIND>(ta, stream);
+    case 64: return launch_tiles_LHD<L, 4, DV, KIND>(ta, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 template <int L, int DV>
 static hipError_t launch_tiles_LD(const TilesArgs& ta, hipStream_t stream) {
-  hipError_t e = ta.p.H == 32 ? launch_tiles_LHD<L, 2, DV, 1>(ta, stream) : launch_tiles_LHD<L, 1, DV, 1>(ta, stream);
+  const hipError_t e = launch_tiles_LDK<L, DV, 1>(ta, stream);
   if (e != hipSuccess || ta.p.n_dense <= 0) return e;
-  return ta.p.H == 32 ? launch_tiles_LHD<L, 2, DV, 2>(ta, stream) : launch_tiles_LHD<L, 1, DV, 2>(ta, stream);
+  return launch_tiles_LDK<L, DV, 2>(ta, stream);
 }
 
 // The tile launches of the row-tile form: sparse-row tiles, then dense-window tiles.  a: as for the hybrid launch of the

@@ -418,11 +418,13 @@ hipError_t launch_dense_update_leftover(const float* in, const float* W, long lo
                                         int D, int H, const int* plan, int off_tasks, int n_wide, int off_fixups,
                                         int n_split_rows, int off_slice_tasks, int n_slice_tasks, hipStream_t stream) {
   if (N <= 0 || (long long)n_wide + n_split_rows + n_slice_tasks <= 0) return hipSuccess;
-  if (!dense_update_streams(in, out, D, H) || H > 32) return hipErrorInvalidValue;
-  return H == 32 ? launch_rows<2>(in, W, ldr, ldc, out, D, plan, off_tasks, n_wide, off_fixups, n_split_rows, off_slice_tasks,
-                                  n_slice_tasks, stream)
-                 : launch_rows<1>(in, W, ldr, ldc, out, D, plan, off_tasks, n_wide, off_fixups, n_split_rows, off_slice_tasks,
-                                  n_slice_tasks, stream);
+  if (!dense_update_streams(in, out, D, H) || (H != 16 && H != 32 && H != 64)) return hipErrorInvalidValue;
+#define HCSPMM_ROWS_CASE(T_) \
+  return launch_rows<T_>(in, W, ldr, ldc, out, D, plan, off_tasks, n_wide, off_fixups, n_split_rows, off_slice_tasks, n_slice_tasks, stream);
+  if (H == 64) { HCSPMM_ROWS_CASE(4) }
+  if (H == 32) { HCSPMM_ROWS_CASE(2) }
+  HCSPMM_ROWS_CASE(1)
+#undef HCSPMM_ROWS_CASE
 }
 
 }  // namespace hcspmm

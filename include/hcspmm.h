@@ -309,7 +309,7 @@ int32_t hcspmm_wide_threshold_typed(const hcspmm_plan_header* header_h, int embe
  *   rows of out2 from the registers, park the 16 x D tile in a wave-private LDS area and run the update's MFMA chain on
  *   it (weights staged in LDS once per workgroup), so out2 is never read back.  Rows summed by whole waves or in pieces
  *   (wide tasks, split and column-sliced rows) stay in the hybrid launch and are multiplied by a small launch behind the
- *   fix-up pass.  fp32, D a multiple of 16 in [32, 128], H = 16 or 32, sparse region in one column pass (D < 64, or a
+ *   fix-up pass.  fp32, D a multiple of 16 in [32, 128], H = 16, 32 or 64, sparse region in one column pass (D < 64, or a
  *   short-row graph, or hcspmm_plan_params.panel_cols < 0).  +8 ... +34 % over form 0 on graphs of a million rows and
  *   more at D <= 64 (profiles/r03/ab_fused_rows.log) -- chosen automatically there; opt-in elsewhere.
  * 1, in-launch (round 2; plans built with fuse_in_launch = 1, dense-tile windows only): the aggregation runs with

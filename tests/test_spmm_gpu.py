@@ -462,7 +462,7 @@ def test_fused_variants(oracle_mod, dev, fe, gname, gen, D, H, form):
     h = g.header()
     # in the launch: asked for, fp32, D a multiple of 16 from 32 up, H = 16 or 32 (output tiles held in registers), W fits the LDS staging area
     dense_ok = D % 16 == 0 and D >= 32 and H in (16, 32) and D * (H + 4) * 4 <= 64 * 1024
-    rows_ok = D % 16 == 0 and 32 <= D <= 128 and H in (16, 32)
+    rows_ok = D % 16 == 0 and 32 <= D <= 128 and H in (16, 32, 64) and (D * (H + 4) + 4 * (16 * (D + 4) + 16)) * 4 <= 64 * 1024
     assert hcspmm.fused_in_launch(g.row_nzr, D, H) == (2 if asked == 2 and rows_ok else (1 if asked == 1 and h.n_dense > 0 and dense_ok else 0))
     if gname not in ("powerlaw", "hubs"):
         assert h.n_dense > 0
@@ -500,7 +500,7 @@ def test_fused_variants(oracle_mod, dev, fe, gname, gen, D, H, form):
     assert np.array_equal(out2.cpu().numpy(), zi) and np.array_equal(out.cpu().numpy(), zi.astype(np.float64) @ Wi.astype(np.float64))
 
 
-@pytest.mark.parametrize("D,H", [(32, 32), (64, 16)])
+@pytest.mark.parametrize("D,H", [(32, 32), (64, 16), (64, 64)])
 def test_fused_row_tiles_are_automatic_on_million_row_graphs(oracle_mod, dev, fe, D, H):
     """A graph of a million rows and more takes the row-tile form without being asked (out2 is far beyond what the update
     launch finds in the caches); a plan built with fuse_in_launch = -1 keeps two launches.  Same bits in out2 AND out; exact

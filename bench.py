@@ -813,8 +813,8 @@ def main():
 
 def fused_block(dev, graph_of, wl="rd_like", D=32, H=32, steps=30):
     """The fused aggregate+update operator (the GCN-backward shape) on the RD-sized low-degree graph of the sweep:
-    two launches (a plan built with fuse_in_launch = -1) against the row-tile form the operator picks by itself from a million
-    rows on -- HIP events around `steps` calls each, same graph, same tensors, out compared bit for bit.
+    two launches (a plan built with fuse_in_launch = -1) against the row-tile form the operator picks by itself when the
+    aggregate is 80 MB or more -- HIP events around `steps` calls each, same graph, same tensors, out compared bit for bit.
     Not part of `value`; never takes the headline down."""
     import torch
     import hcspmm
@@ -851,7 +851,7 @@ def fused_block(dev, graph_of, wl="rd_like", D=32, H=32, steps=30):
                "chosen_form_ms": t_auto, "gain_percent": 100.0 * (t_two - t_auto) / t_two, "spmm_alone_ms": t_spmm,
                "out_and_out2_bit_identical_between_forms": same, "steps": steps,
                "note": "form 2 = 16-row tiles of both sub-paths summed, parked in LDS and multiplied by W before they leave the CU "
-                       "(csrc/fused_rows.hip); chosen automatically from a million rows on at dim <= 64"}
+                       "(csrc/fused_rows.hip); chosen automatically when out2 is 80 MB or more at dim <= 64"}
         del outs, never, X, W, o_two, o_auto
         torch.cuda.empty_cache()
         return res

@@ -332,10 +332,11 @@ extern "C" int hcspmm_forward(const float* X, float* Z, const int32_t* rowptr, c
 // whose rows (a few thousand) a small launch multiplies behind the fix-up pass.  `out` has form 0's bits.  Needs the sparse
 // region in ONE column pass (D < 64, or a short-row graph), 32 <= D <= 128, D % 16 == 0, H = 16, 32 or 64.
 // Which one: HCSPMM_FUSED_SINGLE_LAUNCH=0 / 1 / 2 in the environment, else the plan's flags (fuse_in_launch = -1 / 1 / 2),
-// else automatic: form 2 for graphs of at least a million rows at D <= 64 -- out2 is then far beyond what the update launch
-// finds in the caches, and not re-reading it is worth +8 ... +34 % (profiles/r03/ab_fused_rows.log: TT / RD / YeastH-sized
-// low-degree graphs, the dense-heavy 1-2 M-node graphs); at Reddit scale (233 K rows, out2 = 30 MB, cache-resident) it is
-// 1-2 % slower than two launches, and beyond 64 columns the tiles' LDS area caps the occupancy (-3 ... +12 %), so those stay
+// else automatic: form 2 when out2 (N x D fp32) is 80 MB or more at D <= 64 -- it is then beyond what the update launch
+// finds in the caches next to X and out, and not re-reading it is worth +2 ... +34 % (profiles/r03/ab_fused_rows.log: TT / RD /
+// YeastH-sized low-degree graphs and dense-heavy graphs from 1/5 of their size up; every point above 80 MB gains, every
+// sparse-row point below it loses 4-20 % -- the cache-resident Reddit-scale graph 1-2 %); beyond 64 columns the tiles' LDS
+// area caps the occupancy (-3 ... +12 %), so those stay
 // opt-in.  A shape outside a form falls back to the next one down.
 static int fused_form(const hcspmm_plan_header* ph, const void* X, const void* out2, const void* out, int D, int H,
                       const void* workspace = nullptr) {
@@ -349,7 +350,7 @@ static int fused_form(const hcspmm_plan_header* ph, const void* X, const void* o
     if (ph->flags & HCSPMM_PLAN_FUSE_NEVER) asked = 0;
     else if (ph->flags & HCSPMM_PLAN_FUSE_ROWS) asked = 2;
     else if (ph->flags & HCSPMM_PLAN_FUSE_IN_LAUNCH) asked = 1;
-    else asked = (ph->num_nodes >= 1000000 && D <= 64) ? 2 : 0;
+    else asked = ((double)ph->num_nodes * (double)D * 4.0 >= 80e6 && D <= 64) ? 2 : 0;  // out2 of 80 MB and more
   }
   if (asked == 0) return 0;
   // both forms are 16-byte-per-lane builds: a caller's workspace that is only 4- or 8-byte aligned takes the two-launch form

@@ -77,10 +77,13 @@ def main():
             slice_kw = dict(slice_threshold=int(rng.choice([1, 2, 5, 16, 40])), n_slices=int(rng.choice([8, 16, 24, 32])))
             seg = int(rng.choice([0, 0, 3, 16]))
             g.row_nzr = fe.build_plan(g.rp_d, g.col_d, g.bp, g.e2c, g.ht, segment_len=seg, split_threshold=2 * seg, **slice_kw)
-        X = rng.standard_normal((N, D)).astype(np.float32)
         strided = mode != "plan_free" and rng.random() < 0.3  # X and Z as column slices of wider matrices
         fused = dtype == torch.float32 and mode != "plan_free" and not strided and rng.random() < 0.35
         in_launch = int(rng.choice([0, 1, 2, 2])) if fused else 0
+        H_pick = None
+        if in_launch == 2 and rng.random() < 0.8:  # mostly shapes the row-tile form serves (others fall back to two launches)
+            D, H_pick = int(rng.choice([32, 48, 64, 96, 128])), int(rng.choice([16, 32, 64]))
+        X = rng.standard_normal((N, D)).astype(np.float32)
         if in_launch:  # the same classification, plan flagged so that dense windows (1) / every tile (2: row-tile form; one column
             # pass forced half of the time so that wide embeddings take it too) are multiplied inside the aggregation launches
             g.row_nzr = fe.build_plan(g.rp_d, g.col_d, g.bp, g.e2c, g.ht, fuse_in_launch=in_launch,
@@ -100,7 +103,7 @@ def main():
             return wide_z[:, offz:offz + D].contiguous()
         try:
             if fused:
-                H = int(rng.choice([16, 32, 32, 32, 7, 64, 48]))
+                H = H_pick if H_pick else int(rng.choice([16, 32, 32, 32, 7, 64, 48]))
                 Wm = rng.standard_normal((D, H)).astype(np.float32)
                 Xd, Wd = torch.from_numpy(X).to(dev), torch.from_numpy(Wm).to(dev)
                 out, out2 = fe.forward_fixed32_fused(Xd, *g.args(), Wd)

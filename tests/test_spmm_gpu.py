@@ -502,8 +502,8 @@ def test_fused_variants(oracle_mod, dev, fe, gname, gen, D, H, form):
 
 @pytest.mark.parametrize("D,H", [(32, 32), (64, 16), (64, 64)])
 def test_fused_row_tiles_are_automatic_on_million_row_graphs(oracle_mod, dev, fe, D, H):
-    """A graph of a million rows and more takes the row-tile form without being asked (out2 is far beyond what the update
-    launch finds in the caches); a plan built with fuse_in_launch = -1 keeps two launches.  Same bits in out2 AND out; exact
+    """A graph whose aggregate (N x D fp32) is 80 MB or more takes the row-tile form without being asked (out2 is then beyond
+    what the update launch finds in the caches); a plan built with fuse_in_launch = -1 keeps two launches.  Same bits in out2 AND out; exact
     integer checksums over every row of both sub-paths; sampled rows against the oracle.  (Composite graph: compact dense
     windows, tiny / ordinary / wide / split / column-sliced rows.)"""
     rp, col = graphs.planted_dense_graph_fast(1100000, seed=5, dense_fraction=0.4, k_cols=12, fill=0.5, sparse_degree=3)

@@ -43,6 +43,8 @@ def child():
     out = {}
     for wl in sys.argv[2].split(","):
         n_local, e_local, _, vw, _ = bench.WORKLOADS[wl]
+        scale = float(os.environ.get("AB_SCALE", 1.0))  # the same generator at a fraction of the size (crossover of the forms)
+        n_local, e_local = int(n_local * scale) // 16 * 16, int(e_local * scale)
         if vw != 1:  # the fused operators are square (out2 has the graph's rows): use the block's own columns only
             from hcspmm import graphs
             rp, col = graphs.planted_powerlaw_block(n_local, n_local, e_local, seed=3)

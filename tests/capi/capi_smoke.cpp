@@ -110,6 +110,58 @@ int main() {
         return 5;
       }
   }
+  // fused aggregate + update (hcspmm_forward_fused: out2 = A*X, out = out2*W) in the two-launch form and in the row-tile
+  // form (a plan built with fuse_in_launch = 2): small integer operands, so both must be EXACT and identical
+  {
+    const int H = 32;
+    std::vector<float> Wm((size_t)D * H), want_out((size_t)N * H, 0.0f);
+    for (int d = 0; d < D; ++d)
+      for (int h = 0; h < H; ++h) Wm[(size_t)d * H + h] = (float)((d + 2 * h) % 5 - 2);
+    for (int64_t r = 0; r < N; ++r)
+      for (int h = 0; h < H; ++h) {
+        double acc = 0.0;
+        for (int d = 0; d < D; ++d) acc += (double)want[(size_t)r * D + d] * (double)Wm[(size_t)d * H + h];
+        want_out[(size_t)r * H + h] = (float)acc;  // |acc| < 2^24: exact
+      }
+    float* W_d = upload(Wm);
+    float* out_d = nullptr;
+    HIP_OK(hipMalloc(&out_d, sizeof(float) * (size_t)N * H));
+    std::vector<float> got_out((size_t)N * H);
+    for (int form = 0; form <= 2; form += 2) {
+      hcspmm_plan_params pf = {256, 128, form == 0 ? -1 : 2};
+      int64_t fw = 0;
+      HC_OK(hcspmm_plan_words(rowptr.data(), N, E, bp.data(), ht.data(), &pf, &fw));
+      std::vector<int32_t> fplan((size_t)fw);
+      HC_OK(hcspmm_plan_build(rowptr.data(), col.data(), N, E, N, bp.data(), e2c.data(), ht.data(), &pf, fplan.data(), fw));
+      hcspmm_plan_header fh;
+      std::memcpy(&fh, fplan.data(), sizeof(fh));
+      if (hcspmm_fused_in_launch(&fh, D, H) != form) {
+        std::fprintf(stderr, "fused form %d expected, got %d\n", form, hcspmm_fused_in_launch(&fh, D, H));
+        return 14;
+      }
+      int32_t* fplan_d = upload(fplan);
+      HIP_OK(hipMemsetAsync(Z_d, 0xff, sizeof(float) * (size_t)N * D, stream));
+      HIP_OK(hipMemsetAsync(out_d, 0xff, sizeof(float) * (size_t)N * H, stream));
+      HC_OK(hcspmm_forward_fused(X_d, out_d, Z_d, W_d, H, 1, H, rp_d, col_d, bp_d, e2c_d, e2r_d, ht_d, fplan_d, &fh, N, E, D, ws_d,
+                                 ws_bytes, (void*)stream));
+      HIP_OK(hipMemcpyAsync(got.data(), Z_d, sizeof(float) * got.size(), hipMemcpyDeviceToHost, stream));
+      HIP_OK(hipMemcpyAsync(got_out.data(), out_d, sizeof(float) * got_out.size(), hipMemcpyDeviceToHost, stream));
+      HIP_OK(hipStreamSynchronize(stream));
+      for (size_t i = 0; i < got.size(); ++i)
+        if (got[i] != want[i]) {
+          std::fprintf(stderr, "fused form %d: out2 mismatch at %zu: %g vs %g\n", form, i, got[i], want[i]);
+          return 15;
+        }
+      for (size_t i = 0; i < got_out.size(); ++i)
+        if (got_out[i] != want_out[i]) {
+          std::fprintf(stderr, "fused form %d: out mismatch at %zu: %g vs %g\n", form, i, got_out[i], want_out[i]);
+          return 16;
+        }
+      HIP_OK(hipFree(fplan_d));
+    }
+    HIP_OK(hipFree(W_d));
+    HIP_OK(hipFree(out_d));
+  }
   // bfloat16 features through hcspmm_forward_typed: 16-bit X and Z, fp32 accumulation, one rounding (to nearest
   // even) per output element.  The features are small integers (exact in bf16), so the fp32 sum is exact and
   // the expected output is simply the rounded `want`.

@@ -1,4 +1,4 @@
-// fused_rows.hip -- fused aggregate + update for the SPARSE-ROW path (hcspmm_forward_fused, "row-tile form").
+// fused_rows.hip -- fused aggregate + update with 16-row tiles of BOTH sub-paths (hcspmm_forward_fused, "row-tile form").
 //
 // The reference multiplies the aggregate of a window by the weights inside the aggregation launch for both window
 // types (hybrid_all_kernel.cu:1639-1848 type-0 branch, :2067-2317, :2572-2770): one thread block owns a 16-row
@@ -18,7 +18,7 @@
 // Not handled here: rows summed by whole waves (wide tasks), split rows, column-sliced rows -- a few thousand rows, but up
 // to a quarter of the entries: the hybrid kernel sums them as always (its ordinary / tiny / dense regions empty) and
 // dense_update_rows_kernel multiplies those rows behind the fix-up pass.
-// Applies when the sparse region is ONE column pass (D <= 32, or short-row graphs at any D <= 128): a panel-major
+// Applies when the sparse region is ONE column pass (D < 64, or short-row graphs at any D <= 128): a panel-major
 // launch (Reddit-scale, D >= 64) never has a whole row in one wave, and there re-reading out2 costs 5 % of the step.
 #include <mutex>
 

@@ -15,6 +15,9 @@ namespace hcspmm {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef HCSPMM_UPD_GRID_CAP
+#define HCSPMM_UPD_GRID_CAP 1024  // one resident round of the streaming update; 512: 5-20 % slower, 2048 / 4096: -6 ... +3 % (profiles/r03/ab_update_grid.log)
+#endif
 constexpr int kUpdWaves = 4;
 constexpr int kMaxTiles = 8;  // 16-column output tiles kept in registers per pass (128 columns)
 
@@ -239,7 +242,7 @@ static hipError_t launch_stream(const float* in, const float* W, long long ldr, 
                                 const int* tile_list, int n_tiles, hipStream_t stream) {
   const size_t lds = (size_t)D * (16 * T + 4) * sizeof(float);
   int grid = (n_tiles + kUpdWaves - 1) / kUpdWaves;
-  if (grid > 1024) grid = 1024;  // W is staged once per workgroup: stride over the row tiles
+  if (grid > HCSPMM_UPD_GRID_CAP) grid = HCSPMM_UPD_GRID_CAP;  // W is staged once per workgroup: stride over the row tiles
   hipLaunchKernelGGL((dense_update_stream_kernel<T>), dim3(grid), dim3(kUpdWaves * 64), lds, stream, in, W, ldr, ldc,
                      out, N, D, tile_list, n_tiles);
   return hipGetLastError();

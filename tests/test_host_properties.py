@@ -149,6 +149,49 @@ def test_sliced_plan_covers_every_entry_exactly_once(capi, g, rule, thr, S, seg)
 
 
 @settings(**SETTINGS)
+@given(csr_graphs(), st.sampled_from([0, 2]), st.sampled_from([0, 3, 9]), st.sampled_from([2, 5, 40]), st.sampled_from([32, 64, 128]))
+def test_row_tile_form_writes_every_out_row_exactly_once(capi, g, rule, thr, split, D):
+    """The row-tile form of the fused operators (csrc/fused_rows.hip, capi.hip hcspmm_forward_fused) writes `out` from three
+    places, each enumerating rows from the plan: the tile launches (whole rows among the ordinary tasks behind the n_wide
+    longest, and among the tiny tasks; every row of a dense window), and dense_update_rows_kernel (whole rows among the n_wide
+    longest tasks, every fix-up entry, slice descriptors with a direct store).  Whatever the split / slice / wide
+    thresholds: those sets are disjoint and their union is [0, N)."""
+    rp, col = g
+    N, E = len(rp) - 1, len(col)
+    W = (N + 15) // 16
+    bp, e2c, e2r, ht, _, _ = hcspmm.preprocess(torch.from_numpy(col), torch.from_numpy(rp), N, E, W, rule=rule)
+    plan_t = hcspmm.build_plan(torch.from_numpy(rp), torch.from_numpy(col), bp, e2c, ht, slice_threshold=thr if thr else -1,
+                               split_threshold=split, segment_len=max(1, split // 2), fuse_in_launch=2, panel_cols=-1)
+    plan = plan_t.numpy()
+    h, tasks, dindex, fix = _decode_plan(plan)
+    assert h.flags == 2
+    thr_wide = capi.lib().hcspmm_wide_threshold(ctypes.byref(h), D)
+    first_tiny = h.n_tasks - h.n_tiny
+    n_wide = int((tasks[:first_tiny, 2] > thr_wide).sum()) if first_tiny else 0
+    assert np.all(tasks[:n_wide, 2] > thr_wide)  # the wide tasks are a prefix of the (length-sorted) list
+    written = np.zeros(N, np.int32)
+    for row, e0, ln, slot in tasks[n_wide:first_tiny]:      # tile launch, ordinary tasks
+        if slot < 0:
+            written[row] += 1
+    for x, i0, ln, i1 in tasks[first_tiny:]:                # tile launch, tiny tasks
+        if x >= 0:
+            written[x] += 1
+    for w in dindex[:, 0]:                                   # tile launch, dense windows
+        written[16 * w:min(16 * w + 16, N)] += 1
+    for row, e0, ln, slot in tasks[:n_wide]:                 # leftover launch: whole rows among the wide tasks
+        if slot < 0:
+            written[row] += 1
+    for row in fix[:, 0]:                                    # ... rows completed by the fix-up pass
+        written[row] += 1
+    if h.n_slices:                                           # ... sliced rows that fell into one piece (direct store)
+        desc = plan[h.off_slice_tasks:h.off_slice_tasks + 4 * h.n_slice_tasks].reshape(-1, 4)
+        for row, e0, ln, slot in desc:
+            if row >= 0 and slot < 0:
+                written[row] += 1
+    assert np.all(written == 1), np.nonzero(written != 1)[0][:10]
+
+
+@settings(**SETTINGS)
 @given(csr_graphs(), st.sampled_from(["new_direct", "new"]))
 def test_loi_reorder_is_a_permutation_and_relabelling_is_an_isomorphism(g, variant):
     rp, col = g

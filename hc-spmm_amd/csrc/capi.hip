@@ -335,8 +335,10 @@ extern "C" int hcspmm_forward(const float* X, float* Z, const int32_t* rowptr, c
 // else automatic: form 2 when out2 (N x D fp32) is 80 MB or more at D <= 64 -- it is then beyond what the update launch
 // finds in the caches next to X and out, and not re-reading it is worth +2 ... +34 % (profiles/r03/ab_fused_rows.log: TT / RD /
 // YeastH-sized low-degree graphs and dense-heavy graphs from 1/5 of their size up; every point above 80 MB gains, every
-// sparse-row point below it loses 4-20 % -- the cache-resident Reddit-scale graph 1-2 %); beyond 64 columns the tiles' LDS
-// area caps the occupancy (-3 ... +12 %), so those stay
+// sparse-row point below it loses 4-20 % -- the cache-resident Reddit-scale graph 1-2 %).  Beyond 64 columns (whole-row tiles
+// up to 112 columns, two column chunks of 64 with eight-wave workgroups at 128) the tiles' LDS area costs occupancy: with
+// H <= 32 graphs with a quarter of their rows in dense-tile windows gain 5-22 % (automatic from 256 MB of out2), sparse-row
+// graphs -2 ... +4 %, and H = 64 is mixed (-6 ... +4 %), so those stay
 // opt-in.  A shape outside a form falls back to the next one down.
 static int fused_form(const hcspmm_plan_header* ph, const void* X, const void* out2, const void* out, int D, int H,
                       const void* workspace = nullptr) {
@@ -350,7 +352,11 @@ static int fused_form(const hcspmm_plan_header* ph, const void* X, const void* o
     if (ph->flags & HCSPMM_PLAN_FUSE_NEVER) asked = 0;
     else if (ph->flags & HCSPMM_PLAN_FUSE_ROWS) asked = 2;
     else if (ph->flags & HCSPMM_PLAN_FUSE_IN_LAUNCH) asked = 1;
-    else asked = ((double)ph->num_nodes * (double)D * 4.0 >= 80e6 && D <= 64) ? 2 : 0;  // out2 of 80 MB and more
+    else {
+      const double out2_bytes = (double)ph->num_nodes * (double)D * 4.0;
+      const bool dense_heavy = 64.0 * (double)ph->n_dense >= (double)ph->num_nodes;  // a quarter of the rows in dense-tile windows
+      asked = (D <= 64 ? out2_bytes >= 80e6 : (D <= 128 && H <= 32 && dense_heavy && out2_bytes >= 256e6)) ? 2 : 0;
+    }
   }
   if (asked == 0) return 0;
   // both forms are 16-byte-per-lane builds: a caller's workspace that is only 4- or 8-byte aligned takes the two-launch form

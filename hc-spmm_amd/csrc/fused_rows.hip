@@ -87,14 +87,15 @@ __device__ __forceinline__ void wave_lds_fence() {
 // 16 consecutive ordinary tasks: 16/R rounds of R tasks, one lane group each
 template <int L, int U>
 __device__ __forceinline__ void ordinary_tile(const PlanArgs& a, const int4* __restrict__ tasks, int base, int ord_end,
-                                              float* __restrict__ tile, int* __restrict__ trow, int TS, int lane) {
+                                              float* __restrict__ tile, int* __restrict__ trow, int TS, int lane, int col0, int width) {
   typedef Lane<F32, 4> Ln;
   constexpr int R = 64 / L;
   const float* X = reinterpret_cast<const float*>(a.X);
   float* Z = reinterpret_cast<float*>(a.Z);
   const int g = lane / L, s = lane & (L - 1);
-  const int c = s * 4;
-  const bool cok = c < a.D;
+  const int cl = s * 4;      // column inside the chunk = column of the tile
+  const int c = col0 + cl;   // feature column
+  const bool cok = cl < width;
   const int csafe = cok ? c : 0;
 #pragma unroll 1
   for (int t = 0; t < 16 / R; ++t) {
@@ -106,7 +107,7 @@ __device__ __forceinline__ void ordinary_tile(const PlanArgs& a, const int4* __r
       if (d.w < 0) Ln::store(Z + (size_t)d.x * a.ldz + c, acc);
       else Ln::store_partial(a.partial + (size_t)d.w * (size_t)a.D + c, acc);
     }
-    if (cok) *reinterpret_cast<f32x4*>(tile + (t * R + g) * TS + c) = acc;
+    if (cok) *reinterpret_cast<f32x4*>(tile + (t * R + g) * TS + cl) = acc;
     if (s == 0) trow[t * R + g] = (d.x >= 0 && d.w < 0) ? d.x : -1;  // a whole row: a row of out; segments wait for the fix-up pass
   }
 }
@@ -114,15 +115,16 @@ __device__ __forceinline__ void ordinary_tile(const PlanArgs& a, const int4* __r
 // 16 consecutive tiny tasks (<= 2 entries, indices in the descriptor): T per lane group at a time, as tiny_tasks does
 template <int L>
 __device__ __forceinline__ void tiny_tile(const PlanArgs& a, const int4* __restrict__ tasks, int base, float* __restrict__ tile,
-                                          int* __restrict__ trow, int TS, int lane) {
+                                          int* __restrict__ trow, int TS, int lane, int col0, int width) {
   typedef Lane<F32, 4> Ln;
   constexpr int R = 64 / L;
   constexpr int T = R >= 16 ? 1 : 2;
   const float* X = reinterpret_cast<const float*>(a.X);
   float* Z = reinterpret_cast<float*>(a.Z);
   const int g = lane / L, s = lane & (L - 1);
-  const int c = s * 4;
-  const bool cok = c < a.D;
+  const int cl = s * 4;
+  const int c = col0 + cl;
+  const bool cok = cl < width;
   const int csafe = cok ? c : 0;
 #pragma unroll 1
   for (int st = 0; st < 16 / (R * T); ++st) {
@@ -161,7 +163,7 @@ __device__ __forceinline__ void tiny_tile(const PlanArgs& a, const int4* __restr
         else Ln::store_partial(a.partial + (size_t)(-(d[t].x + 1)) * (size_t)a.D + c, acc);
       }
       const int tr = (st * T + t) * R + g;
-      if (cok) *reinterpret_cast<f32x4*>(tile + tr * TS + c) = acc;
+      if (cok) *reinterpret_cast<f32x4*>(tile + tr * TS + cl) = acc;
       if (s == 0) trow[tr] = (d[t].z >= 0 && d[t].x >= 0) ? d[t].x : -1;
     }
   }
@@ -171,14 +173,14 @@ __device__ __forceinline__ void tiny_tile(const PlanArgs& a, const int4* __restr
 // written to Z and to the LDS tile (register r of lane (kq, j) is row 4*kq + r, columns c .. c + DV)
 template <int DV>
 __device__ __forceinline__ void dense_tile(const PlanArgs& a, int unit, float* __restrict__ tile, int* __restrict__ trow, int TS,
-                                           int lane) {
+                                           int lane, int p0, int p1) {
   const float* X = reinterpret_cast<const float*>(a.X);
   float* Z = reinterpret_cast<float*>(a.Z);
   const int kq = lane >> 4, j = lane & 15;
   const int n_reg = a.n_dense - a.n_dense_compact - a.n_dense_compact2;
   int window;
 #define HCSPMM_TILE_PANELS(CHAIN)                                                         \
-  for (int panel = 0; panel < a.n_panels; ++panel) {                                      \
+  for (int panel = p0; panel < p1; ++panel) {                                              \
     const int c = panel * 16 * DV + j * DV;                                               \
     const bool cok = c < a.D;                                                             \
     const int csafe = cok ? c : 0;                                                        \
@@ -190,7 +192,7 @@ __device__ __forceinline__ void dense_tile(const PlanArgs& a, int unit, float* _
       _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                     \
         typename AccT<DV>::type o;                                                        \
         _Pragma("unroll") for (int q = 0; q < DV; ++q) aset(o, q, acc[q][r]);             \
-        *reinterpret_cast<typename AccT<DV>::type*>(tile + (4 * kq + r) * TS + c) = o;    \
+        *reinterpret_cast<typename AccT<DV>::type*>(tile + (4 * kq + r) * TS + c - p0 * 16 * DV) = o; \
       }                                                                                   \
     }                                                                                     \
   }
@@ -220,26 +222,30 @@ __device__ __forceinline__ void dense_tile(const PlanArgs& a, int unit, float* _
   if (lane < 16) trow[lane] = (window * 16 + lane < a.N) ? window * 16 + lane : -1;
 }
 
-// out[row] = tile[row] * W: the MFMA chain of dense_update_stream_kernel with the A operand read from LDS
+// oacc += tile[:, 0 .. kcols) * W[kbase .. kbase + kcols, :]: the MFMA chain of dense_update_stream_kernel with the A operand read
+// from LDS (s_wk = the staged weights from row kbase on); chunks in ascending k keep that kernel's order of additions
 template <int HT>
-__device__ __forceinline__ void tile_update(const float* __restrict__ tile, const int* __restrict__ trow,
-                                            const float* __restrict__ s_w, int TS, int D, float* __restrict__ out, int lane) {
+__device__ __forceinline__ void tile_mac(const float* __restrict__ tile, const float* __restrict__ s_wk, int TS, int kcols, int lane,
+                                         f32x4 (&oacc)[HT]) {
   constexpr int H = 16 * HT, HS = H + 4;
   const int i = lane & 15, kq = lane >> 4;
-  f32x4 oacc[HT];
-#pragma unroll
-  for (int t = 0; t < HT; ++t) oacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float* trd = tile + i * TS + 4 * kq;
 #pragma unroll 2
-  for (int k0 = 0; k0 < D; k0 += 16) {
+  for (int k0 = 0; k0 < kcols; k0 += 16) {
     const f32x4 av = *reinterpret_cast<const f32x4*>(trd + k0);
-    const float* wrow = s_w + (k0 + 4 * kq) * HS + HT * i;
+    const float* wrow = s_wk + (k0 + 4 * kq) * HS + HT * i;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
 #pragma unroll
       for (int t = 0; t < HT; ++t) oacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], wrow[q * HS + t], oacc[t], 0, 0, 0);
     }
   }
+}
+
+template <int HT>
+__device__ __forceinline__ void tile_store(const int* __restrict__ trow, const f32x4 (&oacc)[HT], float* __restrict__ out, int lane) {
+  constexpr int H = 16 * HT;
+  const int i = lane & 15, kq = lane >> 4;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int orow = trow[4 * kq + r];
@@ -267,19 +273,23 @@ __device__ __forceinline__ void tile_update(const float* __restrict__ tile, cons
 // wide tasks as well -- was built and measured: 140 bytes of scratch at five waves (-25 %), +3.7 % / -4.4 % / +7.8 % on the
 // TT / RD / YeastH-sized graphs at four, against +9.0 / +4.0 / +9.0 % for the split (profiles/r03/ab_fused_rows.log).
 // ------------------------------------------------------------------------------------------
-template <int L, int HT, int DV, int KIND>
-__global__ __launch_bounds__(kThreads, KIND == 1 ? HCSPMM_ROWS_MIN_WAVES : HCSPMM_DENSE_TILES_MIN_WAVES) void fused_tiles_kernel(TilesArgs ta) {
+// WV waves per workgroup.  Embeddings wider than 64 columns (WV = 8, ta.chunk < D) are summed in column chunks of at most 64:
+// the tile in LDS is 16 x chunk, the update accumulates `out` over the chunks in ascending k (the same order of additions),
+// and eight waves share one staged copy of the weights -- a whole-width tile (16 x (D + 4) words per wave) next to W capped
+// the sparse-tile launch at three workgroups per CU at D = 128.
+template <int L, int HT, int DV, int KIND, int WV>
+__global__ __launch_bounds__(64 * WV, (KIND == 1 && WV == 4) ? HCSPMM_ROWS_MIN_WAVES : HCSPMM_DENSE_TILES_MIN_WAVES) void fused_tiles_kernel(TilesArgs ta) {
   extern __shared__ __attribute__((aligned(16))) float s_mem[];
   const PlanArgs& a = ta.p;
   constexpr int H = 16 * HT, HS = H + 4;
   constexpr int U = (L < HCSPMM_SPARSE_U) ? L : HCSPMM_SPARSE_U;
-  const int TS = rows_tile_stride(a.D);
+  const int TS = ta.tile_stride;
   float* s_w = s_mem;  // [D][HS]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float* tile = s_mem + a.D * HS + wave * (16 * TS + 16);  // [16][TS] + 16 row ids
   int* trow = reinterpret_cast<int*>(tile + 16 * TS);
-  for (int i = threadIdx.x; i < a.D * H; i += kThreads) {
+  for (int i = threadIdx.x; i < a.D * H; i += 64 * WV) {
     const int k = i / H, h = i - k * H;
     s_w[k * HS + h] = a.W[(long long)k * a.w_ldr + (long long)h * a.w_ldc];
   }
@@ -287,23 +297,60 @@ __global__ __launch_bounds__(kThreads, KIND == 1 ? HCSPMM_ROWS_MIN_WAVES : HCSPM
   const int4* tasks = reinterpret_cast<const int4*>(a.plan + a.off_tasks);
   const int ord_end = a.n_tasks - a.n_tiny;
   const int n_items = KIND == 1 ? ta.n_ord_tiles + ta.n_tiny_tiles : a.n_dense;
+  // column passes of one item of a chunked launch (WV = 8): sparse tiles ceil(D / chunk), dense windows one per panel
+  [[maybe_unused]] const int n_pass = KIND == 1 ? (a.D + ta.chunk - 1) / ta.chunk : a.n_panels;
   // (Requesting the next item's compact record / tiny descriptors one item ahead -- two dependent round trips per tile instead
   // of three -- was built and measured: tiny tiles 3-4 % slower, dense windows -4 ... +5 %: profiles/r03/ab_fused_rows.log.)
-  for (int item = (int)blockIdx.x * kWaves + wave; item < n_items; item += (int)gridDim.x * kWaves) {
-    if constexpr (KIND == 1) {
-      if (item < ta.n_ord_tiles) ordinary_tile<L, U>(a, tasks, a.n_wide + item * 16, ord_end, tile, trow, TS, lane);
-      else tiny_tile<L>(a, tasks, ord_end + (item - ta.n_ord_tiles) * 16, tile, trow, TS, lane);
+  for (int item = (int)blockIdx.x * WV + wave; item < n_items; item += (int)gridDim.x * WV) {
+    if constexpr (WV == kWaves) {
+      // one pass: the tile holds whole rows, and the output accumulators live only while the update runs (kept alive across
+      // the gathers they cost every one of these kernels 12-72 bytes of scratch)
+      if constexpr (KIND == 1) {
+        if (item < ta.n_ord_tiles) ordinary_tile<L, U>(a, tasks, a.n_wide + item * 16, ord_end, tile, trow, TS, lane, 0, a.D);
+        else tiny_tile<L>(a, tasks, ord_end + (item - ta.n_ord_tiles) * 16, tile, trow, TS, lane, 0, a.D);
+      } else {
+        dense_tile<DV>(a, item, tile, trow, TS, lane, 0, a.n_panels);
+      }
+      wave_lds_fence();
+      f32x4 oacc[HT];
+#pragma unroll
+      for (int t = 0; t < HT; ++t) oacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      tile_mac<HT>(tile, s_w, TS, a.D, lane, oacc);
+      tile_store<HT>(trow, oacc, a.out, lane);
+      wave_lds_fence();  // the next tile's writes stay behind these reads
     } else {
-      dense_tile<DV>(a, item, tile, trow, TS, lane);
+      f32x4 oacc[HT];
+#pragma unroll
+      for (int t = 0; t < HT; ++t) oacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+      for (int p = 0; p < n_pass; ++p) {
+        int kbase, kcols;
+        if constexpr (KIND == 1) {
+          kbase = p * ta.chunk;
+          kcols = min(ta.chunk, a.D - kbase);
+          if (item < ta.n_ord_tiles) ordinary_tile<L, U>(a, tasks, a.n_wide + item * 16, ord_end, tile, trow, TS, lane, kbase, kcols);
+          else tiny_tile<L>(a, tasks, ord_end + (item - ta.n_ord_tiles) * 16, tile, trow, TS, lane, kbase, kcols);
+        } else {
+          kbase = p * 16 * DV;
+          kcols = min(16 * DV, a.D - kbase);
+          dense_tile<DV>(a, item, tile, trow, TS, lane, p, p + 1);
+        }
+        wave_lds_fence();
+        tile_mac<HT>(tile, s_w + kbase * HS, TS, kcols, lane, oacc);
+        wave_lds_fence();  // the next chunk's writes stay behind these reads
+      }
+      tile_store<HT>(trow, oacc, a.out, lane);
     }
-    wave_lds_fence();
-    tile_update<HT>(tile, trow, s_w, TS, a.D, a.out, lane);
-    wave_lds_fence();  // the next tile's writes stay behind these reads
   }
 }
 
+// column chunk of the sparse tiles and waves per workgroup for an embedding width
+static inline int tiles_chunk(int D) { return (D > 64 && D % 64 == 0) ? 64 : D; }  // (D = 96 in chunks of 48: 12 of 16 lanes busy, two walks of every task: -25 % on the TT-sized graph)
+static inline int tiles_waves(int D) { return tiles_chunk(D) < D ? 8 : kWaves; }
+static inline int tiles_stride(int D) { return (tiles_chunk(D) < D ? 64 : D) + 4; }  // (dense panels of a chunked launch are 64 wide)
+
 size_t fused_tiles_lds_bytes(int D, int H) {
-  return ((size_t)D * rows_w_stride(H) + (size_t)kWaves * (16 * rows_tile_stride(D) + 16)) * sizeof(float);
+  return ((size_t)D * rows_w_stride(H) + (size_t)tiles_waves(D) * (16 * tiles_stride(D) + 16)) * sizeof(float);
 }
 
 // shapes the row-tile form serves: fp32 rows of 16-byte pieces, one lane group of at most 32 lanes per row, H = 16, 32 or 64
@@ -313,7 +360,7 @@ bool fused_tiles_supported(int D, int H) {
 
 // workgroups the chip holds at once (persistent launch: more than that would queue behind whole strided loops).  Asked once per
 // kernel and LDS size (the occupancy query costs tens of microseconds on the host: not per launch).
-template <int L, int HT, int DV, int KIND>
+template <int L, int HT, int DV, int KIND, int WV>
 static long long resident_wgs(size_t lds) {
   static std::mutex mu;
   static size_t seen_lds[4] = {0, 0, 0, 0};
@@ -323,7 +370,8 @@ static long long resident_wgs(size_t lds) {
     if (seen_wgs[i] > 0 && seen_lds[i] == lds) return seen_wgs[i];
   int per_cu = 0, cus = 0, dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return 1024;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_tiles_kernel<L, HT, DV, KIND>, kThreads, lds) != hipSuccess || per_cu <= 0) per_cu = 4;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_tiles_kernel<L, HT, DV, KIND, WV>, 64 * WV, lds) != hipSuccess || per_cu <= 0)
+    per_cu = 16 / WV;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
   const long long wgs = (long long)per_cu * cus;
   for (int i = 0; i < 4; ++i)
@@ -335,13 +383,15 @@ static long long resident_wgs(size_t lds) {
   return wgs;
 }
 
-template <int L, int HT, int DV, int KIND>
+template <int L, int HT, int DV, int KIND, int WV>
 static hipError_t launch_tiles_LHD(TilesArgs ta, hipStream_t stream) {
   constexpr int R = 64 / L;
   PlanArgs& a = ta.p;
   a.n_wide = (R > 1) ? a.n_wide : 0;
   a.dense_vec = DV;
   a.n_panels = (a.D + 16 * DV - 1) / (16 * DV);
+  ta.chunk = tiles_chunk(a.D);
+  ta.tile_stride = tiles_stride(a.D);
   ta.n_ord_tiles = (a.n_tasks - a.n_tiny - a.n_wide + 15) / 16;
   ta.n_tiny_tiles = (a.n_tiny + 15) / 16;
   const long long items = KIND == 1 ? (long long)ta.n_ord_tiles + ta.n_tiny_tiles : (long long)a.n_dense;
@@ -352,28 +402,28 @@ static hipError_t launch_tiles_LHD(TilesArgs ta, hipStream_t stream) {
   }();
   const size_t lds = fused_tiles_lds_bytes(a.D, a.H);
   // one resident round: every wave strides over the items, so each gets a sample of every class
-  long long grid = (items + kWaves - 1) / kWaves;
-  const long long cap = forced > 0 ? forced : resident_wgs<L, HT, DV, KIND>(lds);
+  long long grid = (items + WV - 1) / WV;
+  const long long cap = forced > 0 ? forced : resident_wgs<L, HT, DV, KIND, WV>(lds);
   if (grid > cap) grid = cap;
-  hipLaunchKernelGGL((fused_tiles_kernel<L, HT, DV, KIND>), dim3((unsigned)grid), dim3(kThreads), lds, stream, ta);
+  hipLaunchKernelGGL((fused_tiles_kernel<L, HT, DV, KIND, WV>), dim3((unsigned)grid), dim3(64 * WV), lds, stream, ta);
   return hipGetLastError();
 }
 
-template <int L, int DV, int KIND>
+template <int L, int DV, int KIND, int WV>
 static hipError_t launch_tiles_LDK(const TilesArgs& ta, hipStream_t stream) {
   switch (ta.p.H) {
-    case 16: return launch_tiles_LHD<L, 1, DV, KIND>(ta, stream);
-    case 32: return launch_tiles_LHD<L, 2, DV, KIND>(ta, stream);
-    case 64: return launch_tiles_LHD<L, 4, DV, KIND>(ta, stream);
+    case 16: return launch_tiles_LHD<L, 1, DV, KIND, WV>(ta, stream);
+    case 32: return launch_tiles_LHD<L, 2, DV, KIND, WV>(ta, stream);
+    case 64: return launch_tiles_LHD<L, 4, DV, KIND, WV>(ta, stream);
     default: return hipErrorInvalidValue;
   }
 }
 
-template <int L, int DV>
+template <int L, int DV, int WV>
 static hipError_t launch_tiles_LD(const TilesArgs& ta, hipStream_t stream) {
-  const hipError_t e = launch_tiles_LDK<L, DV, 1>(ta, stream);
+  const hipError_t e = launch_tiles_LDK<L, DV, 1, WV>(ta, stream);
   if (e != hipSuccess || ta.p.n_dense <= 0) return e;
-  return launch_tiles_LDK<L, DV, 2>(ta, stream);
+  return launch_tiles_LDK<L, DV, 2, WV>(ta, stream);
 }
 
 // The tile launches of the row-tile form: sparse-row tiles, then dense-window tiles.  a: as for the hybrid launch of the
@@ -383,11 +433,12 @@ hipError_t launch_fused_tiles(const PlanArgs& a, hipStream_t stream) {
   if (!fused_tiles_supported(a.D, a.H) || a.panel_cols < a.D) return hipErrorInvalidValue;
   TilesArgs ta;
   ta.p = a;
-  ta.n_ord_tiles = ta.n_tiny_tiles = 0;
+  ta.n_ord_tiles = ta.n_tiny_tiles = ta.chunk = ta.tile_stride = 0;
+  if (tiles_chunk(a.D) < a.D) return launch_tiles_LD<16, 4, 8>(ta, stream);  // D = 128: two chunks of 64
   switch (pick_L(a.D, 4)) {
-    case 8: return launch_tiles_LD<8, 2>(ta, stream);                                                    // D = 32
-    case 16: return a.D >= 64 ? launch_tiles_LD<16, 4>(ta, stream) : launch_tiles_LD<16, 2>(ta, stream);  // D = 48, 64
-    case 32: return launch_tiles_LD<32, 4>(ta, stream);                                                  // D = 80 .. 128
+    case 8: return launch_tiles_LD<8, 2, 4>(ta, stream);                                                       // D = 32
+    case 16: return a.D >= 64 ? launch_tiles_LD<16, 4, 4>(ta, stream) : launch_tiles_LD<16, 2, 4>(ta, stream);  // D = 48, 64
+    case 32: return launch_tiles_LD<32, 4, 4>(ta, stream);                                                     // D = 80, 96, 112
     default: return hipErrorInvalidValue;
   }
 }

@@ -48,6 +48,7 @@ struct PlanArgs {
 struct TilesArgs {
   PlanArgs p;
   int n_ord_tiles, n_tiny_tiles;  // filled by the launcher: tiles of 16 ordinary / tiny tasks
+  int chunk, tile_stride;         // filled by the launcher: feature columns per pass of a sparse tile (D: one pass), words per tile row
 };
 
 // Arguments of the plan-free launch: the reference's seven graph tensors as they are.

@@ -175,7 +175,8 @@ typedef struct hcspmm_plan_params {
   int32_t split_threshold; /* default 512 */
   int32_t segment_len;     /* default 256 */
   int32_t fuse_in_launch;  /* form of hcspmm_forward_fused for this plan (see there): 0 = chosen per call (row tiles when out2 --
-                              N x D fp32 -- is 80 MB or more at D <= 64, else two launches), < 0 = always two launches, 1 = dense-tile
+                              N x D fp32 -- is 80 MB or more at D <= 64, or 256 MB or more at D <= 128, H <= 32 on a graph
+                              with a quarter of its rows in dense-tile windows; else two launches), < 0 = always two launches, 1 = dense-tile
                               windows multiply by the weights inside the hybrid launch (slower on MI355X:
                               profiles/r02/ab_fused.log), 2 = row tiles wherever the shape allows */
   int32_t slice_threshold; /* XCD-affine column slices: 0 = automatic (on for num_columns >= 65536 when at least 5 % of
@@ -310,8 +311,10 @@ int32_t hcspmm_wide_threshold_typed(const hcspmm_plan_header* header_h, int embe
  *   it (weights staged in LDS once per workgroup), so out2 is never read back.  Rows summed by whole waves or in pieces
  *   (wide tasks, split and column-sliced rows) stay in the hybrid launch and are multiplied by a small launch behind the
  *   fix-up pass.  fp32, D a multiple of 16 in [32, 128], H = 16, 32 or 64, sparse region in one column pass (D < 64, or a
- *   short-row graph, or hcspmm_plan_params.panel_cols < 0).  +2 ... +34 % over form 0 wherever out2 is 80 MB or more at
- *   D <= 64 (profiles/r03/ab_fused_rows.log) -- chosen automatically there; opt-in elsewhere (slower on small graphs).
+ *   short-row graph, or hcspmm_plan_params.panel_cols < 0); D = 128 is summed in two column chunks of 64 (eight-wave
+ *   workgroups, `out` accumulated over the chunks in the same order).  +2 ... +34 % over form 0 wherever out2 is 80 MB or
+ *   more at D <= 64, +5 ... +22 % on dense-heavy graphs up to D = 128 with H <= 32 (profiles/r03/ab_fused_rows.log) --
+ *   chosen automatically there; opt-in elsewhere (slower on small graphs).
  * 1, in-launch (round 2; plans built with fuse_in_launch = 1, dense-tile windows only): the aggregation runs with
  *   exchanged MFMA operands, which leaves each lane holding one row of the 16 x D tile in the A-operand shape of the
  *   (tile x weights) MFMAs, so the tile goes from the accumulators straight into the update; windows on the sparse-row

@@ -462,7 +462,9 @@ def test_fused_variants(oracle_mod, dev, fe, gname, gen, D, H, form):
     h = g.header()
     # in the launch: asked for, fp32, D a multiple of 16 from 32 up, H = 16 or 32 (output tiles held in registers), W fits the LDS staging area
     dense_ok = D % 16 == 0 and D >= 32 and H in (16, 32) and D * (H + 4) * 4 <= 64 * 1024
-    rows_ok = D % 16 == 0 and 32 <= D <= 128 and H in (16, 32, 64) and (D * (H + 4) + 4 * (16 * (D + 4) + 16)) * 4 <= 64 * 1024
+    chunked = D == 128  # two column chunks of 64 summed one after the other, eight waves per workgroup
+    lds = (D * (H + 4) + (8 if chunked else 4) * (16 * ((64 if chunked else D) + 4) + 16)) * 4
+    rows_ok = D % 16 == 0 and 32 <= D <= 128 and H in (16, 32, 64) and lds <= 64 * 1024
     assert hcspmm.fused_in_launch(g.row_nzr, D, H) == (2 if asked == 2 and rows_ok else (1 if asked == 1 and h.n_dense > 0 and dense_ok else 0))
     if gname not in ("powerlaw", "hubs"):
         assert h.n_dense > 0
@@ -500,7 +502,7 @@ def test_fused_variants(oracle_mod, dev, fe, gname, gen, D, H, form):
     assert np.array_equal(out2.cpu().numpy(), zi) and np.array_equal(out.cpu().numpy(), zi.astype(np.float64) @ Wi.astype(np.float64))
 
 
-@pytest.mark.parametrize("D,H", [(32, 32), (64, 16), (64, 64)])
+@pytest.mark.parametrize("D,H", [(32, 32), (64, 16), (64, 64), (128, 32), (96, 64)])
 def test_fused_row_tiles_are_automatic_on_million_row_graphs(oracle_mod, dev, fe, D, H):
     """A graph whose aggregate (N x D fp32) is 80 MB or more takes the row-tile form without being asked (out2 is then beyond
     what the update launch finds in the caches); a plan built with fuse_in_launch = -1 keeps two launches.  Same bits in out2 AND out; exact
@@ -520,6 +522,9 @@ def test_fused_row_tiles_are_automatic_on_million_row_graphs(oracle_mod, dev, fe
     g = Graph(rp, col, dev, fe=fe)
     h = g.header()
     assert h.n_dense > 0 and h.n_tiny > 0 and h.n_split_rows > 0 and h.n_slices > 0 and h.n_tasks > h.n_tiny
+    if D > 64 and H > 32:  # beyond 64 columns the form is automatic for H <= 32 on dense-heavy graphs (this one: 40 % of the windows), else opt-in
+        assert hcspmm.fused_in_launch(g.row_nzr, D, H) == 0
+        g.row_nzr = fe.build_plan(g.rp_d, g.col_d, g.bp, g.e2c, g.ht, fuse_in_launch=2)
     assert hcspmm.fused_in_launch(g.row_nzr, D, H) == 2
     never = fe.build_plan(g.rp_d, g.col_d, g.bp, g.e2c, g.ht, fuse_in_launch=-1)
     assert hcspmm.fused_in_launch(never, D, H) == 0

@@ -22,6 +22,14 @@
 // launch (Reddit-scale, D >= 64) never has a whole row in one wave, and there re-reading out2 costs 5 % of the step.
 #include <mutex>
 
+// k-steps per batch of the REGULAR dense chain (windows of more than 80 columns) in this unit only: the dense-tile kernel
+// carries the update state next to the three chains, and the regular chain's batch sets its register allocation (spmm_impl.h's
+// 8 is tuned for the plain kernel).  4 instead of 8: up to 9 % on the dense-heavy graphs at four waves per SIMD; five waves
+// still spill 28-108 bytes and lose (profiles/r03/ab_fused_rows.log v11)
+#ifndef HCSPMM_TILES_DENSE_B
+#define HCSPMM_TILES_DENSE_B 4
+#endif
+#define HCSPMM_DENSE_B HCSPMM_TILES_DENSE_B
 #include "spmm_impl.h"
 
 namespace hcspmm {

@@ -680,6 +680,35 @@ def test_forward_is_hip_graph_capturable(oracle_mod, dev, fe):
     _check(oracle_mod, g, 2 * X, Z)
 
 
+def test_fused_row_tiles_are_hip_graph_capturable(oracle_mod, dev, fe):
+    """The row-tile form of the fused operators is five launches (tile launches, hybrid remainder, fix-up, leftover update) and
+    nothing else -- no synchronisation, no allocation outside torch's allocator, the occupancy query cached by the warm-up
+    call -- so a training step that contains it captures into a HIP graph (HC-SpMM_main.py --graph) and replays on new inputs."""
+    rp, col = graphs.powerlaw_graph(3000, 60000, seed=8, max_degree_frac=0.5)
+    g = Graph(rp, col, dev, fe=fe)
+    g.row_nzr = fe.build_plan(g.rp_d, g.col_d, g.bp, g.e2c, g.ht, fuse_in_launch=2, split_threshold=64, segment_len=32, slice_threshold=40)
+    h = g.header()
+    assert hcspmm.fused_in_launch(g.row_nzr, 32, 32) == 2 and h.n_split_rows > 0 and h.n_slices > 0
+    rng = np.random.default_rng(4)
+    X, W = rng.standard_normal((g.N, 32)).astype(np.float32), rng.standard_normal((32, 32)).astype(np.float32)
+    Xd, Wd = _t(X, dev), _t(W, dev)
+    fe.forward_fixed32_fused(Xd, *g.args(), Wd)  # warm-up outside capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(graph, stream=s):
+            out, out2 = fe.forward_fixed32_fused(Xd, *g.args(), Wd)
+    Xd.copy_(_t(2 * X, dev))
+    graph.replay()
+    torch.cuda.synchronize()
+    want_out, want_out2 = oracle_mod.spmm_fused_f32(rp, col, 2 * X, W)
+    _check(oracle_mod, g, 2 * X, out2)
+    scale = oracle_mod.spmm_f64(rp, col, 2 * X, absolute=True) @ np.abs(W).astype(np.float64)
+    assert np.all(np.abs(out.cpu().numpy().astype(np.float64) - want_out) <= 1e-5 * scale + 1e-30)
+
+
 def test_offsets_beyond_2_to_31_elements(dev):
     """X and Z with more than 2^31 elements (BASELINE config 5 territory: 16 M nodes x 128): row offsets
     must be 64-bit.  9 M nodes x 256 columns = 2.3e9 elements (9.2 GB each); checked with exact

@@ -79,19 +79,19 @@ __global__ __launch_bounds__(kUpdWaves * 64) void dense_update_kernel(const floa
 //    consecutive output columns and leave as one vector store.
 // The accumulation order per output element is a fixed permutation of k (deterministic).
 // ------------------------------------------------------------------------------------------
-template <int T>
+template <int T, bool PAD>  // PAD: H is not 16*T -- the staged weights are zero-padded to 16*T columns, the stores masked
 __global__ __launch_bounds__(kUpdWaves * 64) void dense_update_stream_kernel(const float* __restrict__ in,
                                                                              const float* __restrict__ W,
                                                                              long long ldr, long long ldc,
                                                                              float* __restrict__ out, int N, int D,
-                                                                             const int* __restrict__ tile_list,
+                                                                             int Hreal, const int* __restrict__ tile_list,
                                                                              int n_tiles) {
   extern __shared__ __attribute__((aligned(16))) float s_w[];  // [D][HS], HS = 16*T + 4 (row stride = 4 mod 8 words)
   constexpr int H = 16 * T;
   constexpr int HS = H + 4;
   for (int i = threadIdx.x; i < D * H; i += kUpdWaves * 64) {
     const int k = i / H, h = i - k * H;
-    s_w[k * HS + h] = W[(long long)k * ldr + (long long)h * ldc];
+    s_w[k * HS + h] = (!PAD || h < Hreal) ? W[(long long)k * ldr + (long long)h * ldc] : 0.0f;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -129,10 +129,25 @@ __global__ __launch_bounds__(kUpdWaves * 64) void dense_update_stream_kernel(con
     for (int r = 0; r < 4; ++r) {
       const int orow = r0 + 4 * kq + r;
       if (orow < N) {
-        float* o = out + (size_t)orow * (size_t)H + T * i;
+        float* o = out + (size_t)orow * (size_t)(PAD ? Hreal : H) + T * i;
         // written once, not read by this operator: non-temporal stores (1-4 % on the two-launch form, 9 % on the all-dense
         // graph at D = 32: profiles/r03/ab_fused_rows.log)
-        if constexpr (T == 2) {
+        if constexpr (PAD) {
+          // pieces of T floats that do not fill 16-byte units: plain (cached) stores, so that the L2 assembles whole lines
+          // before they leave (as non-temporal scalar stores the (32, 96) shape ran 3x slower)
+          if constexpr (T % 2 == 0) {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            if ((Hreal & 1) == 0) {  // 8-byte aligned pairs
+#pragma unroll
+              for (int t = 0; t < T; t += 2)
+                if (T * i + t < Hreal) *reinterpret_cast<f32x2*>(o + t) = f32x2{acc[t][r], acc[t + 1][r]};
+              continue;
+            }
+          }
+#pragma unroll
+          for (int t = 0; t < T; ++t)
+            if (T * i + t < Hreal) o[t] = acc[t][r];
+        } else if constexpr (T == 2) {
           typedef float f32x2 __attribute__((ext_vector_type(2)));
           __builtin_nontemporal_store(f32x2{acc[0][r], acc[1][r]}, reinterpret_cast<f32x2*>(o));
         } else if constexpr (T == 4) {
@@ -237,14 +252,14 @@ static hipError_t launch_rows(const float* in, const float* W, long long ldr, lo
   return hipGetLastError();
 }
 
-template <int T>
-static hipError_t launch_stream(const float* in, const float* W, long long ldr, long long ldc, float* out, int N, int D,
+template <int T, bool PAD>
+static hipError_t launch_stream(const float* in, const float* W, long long ldr, long long ldc, float* out, int N, int D, int H,
                                 const int* tile_list, int n_tiles, hipStream_t stream) {
   const size_t lds = (size_t)D * (16 * T + 4) * sizeof(float);
   int grid = (n_tiles + kUpdWaves - 1) / kUpdWaves;
   if (grid > HCSPMM_UPD_GRID_CAP) grid = HCSPMM_UPD_GRID_CAP;  // W is staged once per workgroup: stride over the row tiles
-  hipLaunchKernelGGL((dense_update_stream_kernel<T>), dim3(grid), dim3(kUpdWaves * 64), lds, stream, in, W, ldr, ldc,
-                     out, N, D, tile_list, n_tiles);
+  hipLaunchKernelGGL((dense_update_stream_kernel<T, PAD>), dim3(grid), dim3(kUpdWaves * 64), lds, stream, in, W, ldr, ldc,
+                     out, N, D, H, tile_list, n_tiles);
   return hipGetLastError();
 }
 
@@ -393,9 +408,22 @@ hipError_t launch_weight_grad(const float* A, long long lda, const float* B, lon
   return hipErrorInvalidValue;
 }
 
-bool dense_update_streams(const float* in, const float* out, int D, int H) {
+// Shapes of the LDS-staged streaming kernel: rows of agg in 16-byte pieces (D a multiple of 16, 16-byte aligned), H up to
+// 128.  H = 16, 32, 48, 64 with a 16-byte aligned `out` take vector stores (and are what the fused tile launches reproduce
+// bit for bit); any other H -- the reference's default 22 classes, a 96-column input layer -- pads the staged weights to the
+// next multiple of 16 columns and masks the stores.  (Round 2 sent those to the any-shape kernel below: 1.5-2.4 TB/s against
+// 4.5-5 here: 550 -> ~230 us for (32, 22) on the RD-sized graph.)
+static bool update_streams_exact(const float* in, const float* out, int D, int H) {
   const bool aligned16 = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
   return aligned16 && D % 16 == 0 && H % 16 == 0 && H <= 64 && (size_t)D * (H + 4) * sizeof(float) <= 64 * 1024;
+}
+
+bool dense_update_streams(const float* in, const float* out, int D, int H) { return update_streams_exact(in, out, D, H); }
+
+static bool update_streams_padded(const float* in, int D, int H) {
+  const int Hp = (H + 15) / 16 * 16;
+  return (reinterpret_cast<uintptr_t>(in) & 15) == 0 && D % 16 == 0 && H > 0 && H <= 128 &&
+         (size_t)D * (Hp + 4) * sizeof(float) <= 64 * 1024;
 }
 
 hipError_t launch_dense_update(const float* in, const float* W, long long ldr, long long ldc, float* out, int N,
@@ -403,12 +431,24 @@ hipError_t launch_dense_update(const float* in, const float* W, long long ldr, l
   if (N <= 0 || H <= 0) return hipSuccess;
   if (!tile_list) n_tiles = (N + 15) / 16;
   if (n_tiles <= 0) return hipSuccess;
-  if (dense_update_streams(in, out, D, H)) {
+  if (update_streams_exact(in, out, D, H)) {
     switch (H / 16) {
-      case 1: return launch_stream<1>(in, W, ldr, ldc, out, N, D, tile_list, n_tiles, stream);
-      case 2: return launch_stream<2>(in, W, ldr, ldc, out, N, D, tile_list, n_tiles, stream);
-      case 3: return launch_stream<3>(in, W, ldr, ldc, out, N, D, tile_list, n_tiles, stream);
-      default: return launch_stream<4>(in, W, ldr, ldc, out, N, D, tile_list, n_tiles, stream);
+      case 1: return launch_stream<1, false>(in, W, ldr, ldc, out, N, D, H, tile_list, n_tiles, stream);
+      case 2: return launch_stream<2, false>(in, W, ldr, ldc, out, N, D, H, tile_list, n_tiles, stream);
+      case 3: return launch_stream<3, false>(in, W, ldr, ldc, out, N, D, H, tile_list, n_tiles, stream);
+      default: return launch_stream<4, false>(in, W, ldr, ldc, out, N, D, H, tile_list, n_tiles, stream);
+    }
+  }
+  if (update_streams_padded(in, D, H)) {
+    switch ((H + 15) / 16) {
+      case 1: return launch_stream<1, true>(in, W, ldr, ldc, out, N, D, H, tile_list, n_tiles, stream);
+      case 2: return launch_stream<2, true>(in, W, ldr, ldc, out, N, D, H, tile_list, n_tiles, stream);
+      case 3: return launch_stream<3, true>(in, W, ldr, ldc, out, N, D, H, tile_list, n_tiles, stream);
+      case 4: return launch_stream<4, true>(in, W, ldr, ldc, out, N, D, H, tile_list, n_tiles, stream);
+      case 5: return launch_stream<5, true>(in, W, ldr, ldc, out, N, D, H, tile_list, n_tiles, stream);
+      case 6: return launch_stream<6, true>(in, W, ldr, ldc, out, N, D, H, tile_list, n_tiles, stream);
+      case 7: return launch_stream<7, true>(in, W, ldr, ldc, out, N, D, H, tile_list, n_tiles, stream);
+      default: return launch_stream<8, true>(in, W, ldr, ldc, out, N, D, H, tile_list, n_tiles, stream);
     }
   }
   const int grid = (n_tiles + kUpdWaves - 1) / kUpdWaves;

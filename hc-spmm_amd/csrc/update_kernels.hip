@@ -79,7 +79,10 @@ __global__ __launch_bounds__(kUpdWaves * 64) void dense_update_kernel(const floa
 //    consecutive output columns and leave as one vector store.
 // The accumulation order per output element is a fixed permutation of k (deterministic).
 // ------------------------------------------------------------------------------------------
-template <int T, bool PAD>  // PAD: H is not 16*T -- the staged weights are zero-padded to 16*T columns, the stores masked
+// PAD: H is not 16*T -- the staged weights are zero-padded to 16*T columns, the stores masked.  DPAD: D is even but not a
+// multiple of 16 (the reference's default 22 classes as the INPUT width): rows of agg are read in 8-byte pairs, the staged
+// weights zero-padded to whole 16-row chunks.
+template <int T, bool PAD, bool DPAD = false>
 __global__ __launch_bounds__(kUpdWaves * 64) void dense_update_stream_kernel(const float* __restrict__ in,
                                                                              const float* __restrict__ W,
                                                                              long long ldr, long long ldc,
@@ -89,9 +92,10 @@ __global__ __launch_bounds__(kUpdWaves * 64) void dense_update_stream_kernel(con
   extern __shared__ __attribute__((aligned(16))) float s_w[];  // [D][HS], HS = 16*T + 4 (row stride = 4 mod 8 words)
   constexpr int H = 16 * T;
   constexpr int HS = H + 4;
-  for (int i = threadIdx.x; i < D * H; i += kUpdWaves * 64) {
+  const int Dp = DPAD ? (D + 15) / 16 * 16 : D;
+  for (int i = threadIdx.x; i < Dp * H; i += kUpdWaves * 64) {
     const int k = i / H, h = i - k * H;
-    s_w[k * HS + h] = (!PAD || h < Hreal) ? W[(long long)k * ldr + (long long)h * ldc] : 0.0f;
+    s_w[k * HS + h] = ((!PAD || h < Hreal) && (!DPAD || k < D)) ? W[(long long)k * ldr + (long long)h * ldc] : 0.0f;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -110,7 +114,23 @@ __global__ __launch_bounds__(kUpdWaves * 64) void dense_update_stream_kernel(con
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (rok && k0 + 16 * u < D) a[u] = arow[(k0 >> 2) + 4 * u];
+        if constexpr (DPAD) {
+          typedef float f32x2 __attribute__((ext_vector_type(2)));
+          const int k = k0 + 16 * u + 4 * kq;  // columns k .. k + 3 of this lane's row, as two pairs (D is even)
+          const float* ap = in + (size_t)(rok ? row : 0) * (size_t)D + k;
+          if (rok && k < D) {
+            const f32x2 lo = *reinterpret_cast<const f32x2*>(ap);
+            a[u][0] = lo[0];
+            a[u][1] = lo[1];
+          }
+          if (rok && k + 2 < D) {
+            const f32x2 hi = *reinterpret_cast<const f32x2*>(ap + 2);
+            a[u][2] = hi[0];
+            a[u][3] = hi[1];
+          }
+        } else {
+          if (rok && k0 + 16 * u < D) a[u] = arow[(k0 >> 2) + 4 * u];
+        }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -252,13 +272,13 @@ static hipError_t launch_rows(const float* in, const float* W, long long ldr, lo
   return hipGetLastError();
 }
 
-template <int T, bool PAD>
+template <int T, bool PAD, bool DPAD = false>
 static hipError_t launch_stream(const float* in, const float* W, long long ldr, long long ldc, float* out, int N, int D, int H,
                                 const int* tile_list, int n_tiles, hipStream_t stream) {
-  const size_t lds = (size_t)D * (16 * T + 4) * sizeof(float);
+  const size_t lds = (size_t)(DPAD ? (D + 15) / 16 * 16 : D) * (16 * T + 4) * sizeof(float);
   int grid = (n_tiles + kUpdWaves - 1) / kUpdWaves;
   if (grid > HCSPMM_UPD_GRID_CAP) grid = HCSPMM_UPD_GRID_CAP;  // W is staged once per workgroup: stride over the row tiles
-  hipLaunchKernelGGL((dense_update_stream_kernel<T, PAD>), dim3(grid), dim3(kUpdWaves * 64), lds, stream, in, W, ldr, ldc,
+  hipLaunchKernelGGL((dense_update_stream_kernel<T, PAD, DPAD>), dim3(grid), dim3(kUpdWaves * 64), lds, stream, in, W, ldr, ldc,
                      out, N, D, H, tile_list, n_tiles);
   return hipGetLastError();
 }
@@ -449,6 +469,16 @@ hipError_t launch_dense_update(const float* in, const float* W, long long ldr, l
       case 6: return launch_stream<6, true>(in, W, ldr, ldc, out, N, D, H, tile_list, n_tiles, stream);
       case 7: return launch_stream<7, true>(in, W, ldr, ldc, out, N, D, H, tile_list, n_tiles, stream);
       default: return launch_stream<8, true>(in, W, ldr, ldc, out, N, D, H, tile_list, n_tiles, stream);
+    }
+  }
+  // an even input width that is not a multiple of 16 (22 classes): 8-byte loads of agg, H up to 64
+  if ((reinterpret_cast<uintptr_t>(in) & 7) == 0 && D % 2 == 0 && D >= 2 && H <= 64 &&
+      (size_t)((D + 15) / 16 * 16) * ((H + 15) / 16 * 16 + 4) * sizeof(float) <= 64 * 1024) {
+    switch ((H + 15) / 16) {
+      case 1: return launch_stream<1, true, true>(in, W, ldr, ldc, out, N, D, H, tile_list, n_tiles, stream);
+      case 2: return launch_stream<2, true, true>(in, W, ldr, ldc, out, N, D, H, tile_list, n_tiles, stream);
+      case 3: return launch_stream<3, true, true>(in, W, ldr, ldc, out, N, D, H, tile_list, n_tiles, stream);
+      default: return launch_stream<4, true, true>(in, W, ldr, ldc, out, N, D, H, tile_list, n_tiles, stream);
     }
   }
   const int grid = (n_tiles + kUpdWaves - 1) / kUpdWaves;

@@ -435,7 +435,7 @@ def _wide_window_graph(seed=11):
 
 
 @pytest.mark.parametrize("D,H", [(32, 32), (64, 64), (96, 22), (32, 7), (16, 40), (128, 32), (48, 16), (256, 32), (16, 16),
-                                 (96, 16), (128, 64), (64, 32), (32, 16), (512, 32)])
+                                 (96, 16), (128, 64), (64, 32), (32, 16), (512, 32), (22, 32), (22, 22), (32, 96), (6, 50)])
 @pytest.mark.parametrize("gname,gen", _FUSED_GRAPHS, ids=[g[0] for g in _FUSED_GRAPHS])
 @pytest.mark.parametrize("form", ["two_launches", "in_launch", "row_tiles"])
 def test_fused_variants(oracle_mod, dev, fe, gname, gen, D, H, form):

@@ -10,86 +10,17 @@
 // (LOI.cpp:71), and there is no static 18 269 000-entry table (LOI.cpp:96).
 #include <algorithm>
 #include <cstdint>
+#include <thread>
 #include <vector>
-#if defined(__x86_64__)
-#include <immintrin.h>
-#endif
 
 #include "hcspmm.h"
 #include "host_util.h"
+#include "loi_scan.h"
 
 namespace {
 int loi_reorder_impl(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, int variant, int32_t* perm_out,
                      int32_t* group_sizes_out, int64_t* n_groups_out);
 
-// Position of the first candidate with the largest profit (float)(ones + deg) / (float)(base + deg - shared),
-// strictly greater than every earlier one (and than 0); -1 if none is alive.  LOI.cpp:775-781.
-int64_t scan_best_scalar(const int32_t* deg, const int32_t* shared, const int32_t* alive, int64_t n, int32_t ones,
-                         int32_t base) {
-  int64_t best = -1;
-  float best_profit = 0.0f;
-  for (int64_t i = 0; i < n; ++i) {
-    if (!alive[i]) continue;
-    const float profit = (float)(ones + deg[i]) / (float)(base + deg[i] - shared[i]);
-    if (profit > best_profit) {
-      best = i;
-      best_profit = profit;
-    }
-  }
-  return best;
-}
-
-bool have_avx2() {
-#if defined(__x86_64__)
-  return __builtin_cpu_supports("avx2");
-#else
-  return false;
-#endif
-}
-
-#if defined(__x86_64__)
-// Eight candidates per step: the same int -> float conversions (round to nearest even) and the same IEEE
-// division as the scalar loop; a block is walked lane by lane only when one of its profits beats the running
-// best, so the winner is still the FIRST position holding the maximum.
-__attribute__((target("avx2"))) int64_t scan_best_avx2(const int32_t* deg, const int32_t* shared, const int32_t* alive,
-                                                        int64_t n, int32_t ones, int32_t base) {
-  int64_t best = -1;
-  float best_profit = 0.0f;
-  const __m256i v_ones = _mm256_set1_epi32(ones), v_base = _mm256_set1_epi32(base);
-  int64_t i = 0;
-  for (; i + 8 <= n; i += 8) {
-    const __m256i d = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(deg + i));
-    const __m256i sh = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(shared + i));
-    const __m256 al = _mm256_castsi256_ps(_mm256_loadu_si256(reinterpret_cast<const __m256i*>(alive + i)));
-    const __m256 num = _mm256_cvtepi32_ps(_mm256_add_epi32(v_ones, d));
-    const __m256 den = _mm256_cvtepi32_ps(_mm256_sub_epi32(_mm256_add_epi32(v_base, d), sh));
-    const __m256 profit = _mm256_and_ps(_mm256_div_ps(num, den), al);  // dead lanes price at 0: never > best
-    if (_mm256_movemask_ps(_mm256_cmp_ps(profit, _mm256_set1_ps(best_profit), _CMP_GT_OQ)) != 0) {
-      alignas(32) float p[8];
-      _mm256_store_ps(p, profit);
-      for (int k = 0; k < 8; ++k)
-        if (p[k] > best_profit) {
-          best = i + k;
-          best_profit = p[k];
-        }
-    }
-  }
-  for (; i < n; ++i) {
-    if (!alive[i]) continue;
-    const float profit = (float)(ones + deg[i]) / (float)(base + deg[i] - shared[i]);
-    if (profit > best_profit) {
-      best = i;
-      best_profit = profit;
-    }
-  }
-  return best;
-}
-#else
-int64_t scan_best_avx2(const int32_t* deg, const int32_t* shared, const int32_t* alive, int64_t n, int32_t ones,
-                       int32_t base) {
-  return scan_best_scalar(deg, shared, alive, n, ones, base);
-}
-#endif
 }
 
 extern "C" int hcspmm_loi_reorder(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, int32_t* perm_out,
@@ -155,7 +86,6 @@ int loi_reorder_impl(const int32_t* rowptr, const int32_t* col, int64_t N, int64
   std::vector<int32_t> resi, next_resi;
   std::vector<std::vector<int32_t>> groups;
   auto deg = [&](int32_t v) { return rowptr[v + 1] - rowptr[v]; };
-  const bool use_avx2 = have_avx2();
 
   int32_t gid = 0;
   int64_t seed_scan = 0;
@@ -210,8 +140,7 @@ int loi_reorder_impl(const int32_t* rowptr, const int32_t* col, int64_t N, int64
       //   (ones + deg v) / (ncols + deg v - shared v)
       const int32_t base = first ? ones : ncols;
       const int64_t n_cand = (int64_t)cand.size();
-      const int64_t bp = use_avx2 ? scan_best_avx2(cand_deg.data(), cand_shared.data(), cand_alive.data(), n_cand, ones, base)
-                                  : scan_best_scalar(cand_deg.data(), cand_shared.data(), cand_alive.data(), n_cand, ones, base);
+      const int64_t bp = hcspmm::loi::scan_best(cand_deg.data(), cand_shared.data(), cand_alive.data(), n_cand, ones, base);
       if (bp < 0) break;
       const int32_t best = cand[(size_t)bp];
       cand_alive[(size_t)bp] = 0;
@@ -416,12 +345,28 @@ extern "C" int hcspmm_apply_permutation(const int32_t* rowptr, const int32_t* co
     inv[(size_t)old] = (int32_t)i;
   }
   rowptr_out[0] = 0;
-  for (int64_t i = 0; i < N; ++i) {
-    const int32_t old = perm[i];
-    int32_t o = rowptr_out[i];
-    for (int32_t e = rowptr[old]; e < rowptr[old + 1]; ++e) col_out[o++] = inv[(size_t)col[e]];
-    std::sort(col_out + rowptr_out[i], col_out + o);
-    rowptr_out[i + 1] = o;
+  for (int64_t i = 0; i < N; ++i) rowptr_out[i + 1] = rowptr_out[i] + (rowptr[perm[i] + 1] - rowptr[perm[i]]);
+  // new rows are independent: contiguous ranges of them, balanced by entries, one per host thread
+  const int T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(16, hcspmm::host_threads()), E / 65536));
+  auto fill_rows = [&](int64_t i0, int64_t i1) {
+    for (int64_t i = i0; i < i1; ++i) {
+      const int32_t old = perm[i];
+      int32_t o = rowptr_out[i];
+      for (int32_t e = rowptr[old]; e < rowptr[old + 1]; ++e) col_out[o++] = inv[(size_t)col[e]];
+      std::sort(col_out + rowptr_out[i], col_out + o);
+    }
+  };
+  if (T == 1) {
+    fill_rows(0, N);
+  } else {
+    std::vector<std::thread> th;
+    int64_t i0 = 0;
+    for (int t = 0; t < T; ++t) {
+      const int64_t i1 = t == T - 1 ? N : std::upper_bound(rowptr_out, rowptr_out + N + 1, (int32_t)(E * (t + 1) / T)) - rowptr_out - 1;
+      th.emplace_back(fill_rows, i0, std::max(i0, i1));
+      i0 = std::max(i0, i1);
+    }
+    for (auto& x : th) x.join();
   }
   return HCSPMM_OK;
 }

@@ -533,8 +533,10 @@ backward_final_fused_64 = forward_final_fused_64
 backward_GIN_final_fused = forward_GIN_final_fused
 
 
-def loi_reorder(row_pointers, column_index, variant="new_direct"):
+def loi_reorder(row_pointers, column_index, variant="new_direct", batch=0, list_cap=0, threads=0):
     """LOI layout reorder (LOI.cpp:660-805 + main's output order) -> (perm[N], group_sizes).
+    variant "fast" = the relaxed parallel form (hcspmm_loi_reorder_fast: capped column-list walks, `batch` seeds per round,
+    deterministic for a given (batch, list_cap) whatever `threads`; NOT the reference's permutation -- batch=1, list_cap=-1 is).
     variant "new" = reorder_plus_new (LOI.cpp:505-658, symmetric-graph form); "plus_direct" / "plus" = the windowed
     variants reorder_plus_direct / reorder_plus (LOI.cpp:286-484 / :98-284; defined for graphs of at least 50 rows
     without empty rows -- other inputs raise); a HCSPMM_LOI_* number is accepted as well."""
@@ -545,6 +547,11 @@ def loi_reorder(row_pointers, column_index, variant="new_direct"):
     perm = torch.empty(N, dtype=torch.int32)
     gs = torch.empty(max(N, 1), dtype=torch.int32)
     ng = ctypes.c_int64(0)
+    if variant == "fast":
+        params = (ctypes.c_int32 * 4)(int(batch), int(list_cap), int(threads), 0)
+        check(L.hcspmm_loi_reorder_fast(_ptr(rp), _ptr(col), N, E, ctypes.cast(params, ctypes.c_void_p), _ptr(perm), _ptr(gs),
+                                        ctypes.byref(ng)))
+        return perm, gs[:ng.value].clone()
     v = variant if isinstance(variant, int) else {"new_direct": 0, "new": 1, "plus_direct": 2, "plus": 3}[variant]
     check(L.hcspmm_loi_reorder_variant(_ptr(rp), _ptr(col), N, E, v, _ptr(perm), _ptr(gs), ctypes.byref(ng)))
     return perm, gs[:ng.value].clone()

@@ -75,6 +75,7 @@ SYMBOLS = {
     "hcspmm_weight_grad": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _int, _int, _vp, _sz, _vp]),
     "hcspmm_loi_reorder": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, ctypes.POINTER(_i64)]),
     "hcspmm_loi_reorder_variant": (_int, [_vp, _vp, _i64, _i64, _int, _vp, _vp, ctypes.POINTER(_i64)]),
+    "hcspmm_loi_reorder_fast": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, ctypes.POINTER(_i64)]),
     "hcspmm_apply_permutation": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
 }
 

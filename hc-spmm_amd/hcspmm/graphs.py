@@ -245,6 +245,59 @@ def planted_powerlaw_block(n_rows, n_cols, n_entries, seed=0, rank=0, dense_frac
     return np.cumsum(rp).astype(np.int32), cc.astype(np.int32)
 
 
+def community_graph(num_nodes, num_edges, seed=0, group_rows=(8, 40), pool_cols=(4, 12), links_per_row=(1, 3), shuffle=True):
+    """Community-structured low-degree graph of the paper's RD order (Table II: 4.86 M nodes / 10.1 M entries) whose
+    structure is hidden by the vertex numbering -- the input the LOI reorder (LOI.cpp:660-805) exists for.
+
+    The vertices fall into consecutive groups of `group_rows` rows.  Each group has a column pool of `pool_cols`
+    of its OWN members, and every row of the group links to `links_per_row` distinct pool columns: rows of a group
+    share columns (what LOI groups on, what the dense-tile path's 16-row reuse feeds on), and the columns a group
+    reads lie together once the group does (what the L2 feeds on).  The remaining entries, up to `num_edges`, are
+    power-law noise: uniform rows, columns from a capped power law (hub columns).  With `shuffle` the vertex ids
+    are then permuted uniformly (rows and columns alike), which leaves an isomorphic graph with no 16-row window
+    structure at all.  Returns (row_pointers, column_index, group_of_vertex) -- the last in the FINAL numbering, so a
+    reorder can be scored against the planted truth."""
+    rng = np.random.default_rng(seed)
+    N = int(num_nodes)
+    sizes = rng.integers(group_rows[0], group_rows[1] + 1, N // group_rows[0] + 2)
+    starts = np.concatenate([[0], np.cumsum(sizes)])
+    starts = starts[starts < N]
+    G = starts.shape[0]
+    ends = np.append(starts[1:], N)
+    gsize = ends - starts
+    idx = np.arange(N, dtype=np.int64)
+    grp = np.searchsorted(starts, idx, side="right") - 1
+    K = np.minimum(rng.integers(pool_cols[0], pool_cols[1] + 1, G), gsize)          # pool size per group
+    pool_off = rng.integers(0, 1 << 30, G) % np.maximum(gsize - K + 1, 1)           # pool = K consecutive members
+    lmax = int(links_per_row[1])
+    m = rng.integers(links_per_row[0], lmax + 1, N)                                  # links per row
+    # `lmax` distinct pool slots per row: a random start and stride 1 inside the pool (distinct while m <= K)
+    first = rng.integers(0, 1 << 30, N) % K[grp]
+    j = np.arange(lmax, dtype=np.int64)[None, :]
+    slot = (first[:, None] + j) % K[grp][:, None]
+    ok = (j < m[:, None]) & (j < K[grp][:, None])
+    rows_p = np.broadcast_to(idx[:, None], slot.shape)[ok]
+    cols_p = (starts[grp] + pool_off[grp])[:, None] + slot
+    cols_p = cols_p[ok]
+    n_noise = max(int(num_edges) - rows_p.shape[0], 0)
+    cdf = _capped_powerlaw_cdf(N, 0.02 * N / max(int(num_edges), 1))
+    cperm = rng.permutation(N)
+    draw = int(n_noise * 1.02) + 8
+    rows_n = rng.integers(0, N, draw)
+    cols_n = cperm[np.searchsorted(cdf, rng.random(draw))]
+    rows = np.concatenate([rows_p, rows_n]).astype(np.int64)
+    cols = np.concatenate([cols_p, cols_n]).astype(np.int64)
+    if shuffle:
+        relabel = rng.permutation(N)
+        rows, cols = relabel[rows], relabel[cols]
+        group_of = np.empty(N, np.int32)
+        group_of[relabel] = grp.astype(np.int32)
+    else:
+        group_of = grp.astype(np.int32)
+    rp, col = _to_csr(rows, cols, N)
+    return rp, col, group_of
+
+
 def molecule_graph(num_nodes, seed=0, size_range=(10, 46), heavy_fraction=0.45):
     """Collection of small molecule-like components laid out one after another (the shape of the
     TU-collection datasets in the paper's Table II -- YeastH, OVCAR-8H, ...: millions of nodes, average

@@ -465,6 +465,23 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   }, "-> [perm (old vertex id at each new position), group sizes]; variant 0 = reorder_plus_new_direct, 1 = reorder_plus_new, "
      "2 / 3 = the windowed reorder_plus_direct / reorder_plus (>= 50 rows, no empty rows)",
         pybind11::arg("row_pointers"), pybind11::arg("column_index"), pybind11::arg("variant") = 0);
+  m.def("loi_reorder_fast", [](torch::Tensor row_pointers, torch::Tensor column_index, int batch, int list_cap, int threads) {
+    auto rp = row_pointers.to(torch::kCPU, torch::kInt).contiguous();
+    auto col = column_index.to(torch::kCPU, torch::kInt).contiguous();
+    const int64_t N = rp.numel() - 1, E = col.numel();
+    auto perm = torch::empty({N}, torch::kInt), sizes = torch::empty({std::max<int64_t>(N, 1)}, torch::kInt);
+    int64_t ng = 0;
+    const hcspmm_loi_fast_params params = {batch, list_cap, threads, 0};
+    {
+      pybind11::gil_scoped_release no_gil;  // host threads for a few hundred milliseconds: other Python threads may run
+      check_rc(hcspmm_loi_reorder_fast(rp.data_ptr<int>(), iptr(col), N, E, &params, mptr(perm), sizes.data_ptr<int>(), &ng),
+               "loi_reorder_fast");
+    }
+    return std::vector<torch::Tensor>{perm, sizes.slice(0, 0, ng).clone()};
+  }, "the relaxed parallel LOI reorder (hcspmm.h hcspmm_loi_reorder_fast) -> [perm, group sizes]: NOT the reference's permutation "
+     "unless batch = 1 and list_cap < 0; deterministic for a given (batch, list_cap) whatever the thread count",
+        pybind11::arg("row_pointers"), pybind11::arg("column_index"), pybind11::arg("batch") = 0, pybind11::arg("list_cap") = 0,
+        pybind11::arg("threads") = 0);
   m.def("apply_permutation", [](torch::Tensor row_pointers, torch::Tensor column_index, torch::Tensor perm) {
     auto rp = row_pointers.to(torch::kCPU, torch::kInt).contiguous();
     auto col = column_index.to(torch::kCPU, torch::kInt).contiguous();

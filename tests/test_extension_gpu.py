@@ -135,8 +135,15 @@ def test_extension_host_utilities(HCSPMM):
         assert np.array_equal(perm.numpy(), g["order"]) and np.array_equal(sizes.numpy(), g["group_sizes"])
         perm_n, _ = HCSPMM.loi_reorder(rp, col, 1)
         assert np.array_equal(perm_n.numpy(), g["order_new"])
+        perm_f, sizes_f = HCSPMM.loi_reorder_fast(rp, col, batch=1, list_cap=-1)  # both relaxations off: the reference's order
+        assert np.array_equal(perm_f.numpy(), g["order"]) and np.array_equal(sizes_f.numpy(), g["group_sizes"])
         rp2, col2 = HCSPMM.apply_permutation(rp, col, perm)
         assert rp2.numel() == rp.numel() and int(rp2[-1]) == col.numel() and col2.numel() == col.numel()
+    rp, col, _ = graphs.community_graph(40000, 84000, seed=4)
+    import hcspmm
+    a = HCSPMM.loi_reorder_fast(torch.from_numpy(rp), torch.from_numpy(col))
+    b = hcspmm.loi_reorder(torch.from_numpy(rp), torch.from_numpy(col), variant="fast", threads=3)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     rp, col = graphs.planted_dense_graph(400, seed=3)
     outs = HCSPMM.preprocess(torch.from_numpy(col), torch.from_numpy(rp), 400, len(col), 25)
     info = HCSPMM.plan_info(outs[4])

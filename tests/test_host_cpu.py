@@ -542,6 +542,81 @@ def test_loi_reorder_matches_oracle_on_larger_graph():
     assert sizes.tolist() == [len(x) for x in groups]
 
 
+@pytest.mark.parametrize("path", sorted(p for p in glob.glob(os.path.join(GOLD, "loi_*.npz")) if "loi_win_" not in p))
+def test_fast_loi_with_both_relaxations_off_is_the_reference_permutation(path):
+    """hcspmm_loi_reorder_fast is a different implementation (bitmap placement state, hashed candidate tables, staged growth)
+    of the same greedy: one seed at a time and uncapped list walks must reproduce the fixtures the reference's LOI.cpp made."""
+    g = np.load(path)
+    perm, sizes = hcspmm.loi_reorder(_t(g["row_pointers"]), _t(g["column_index"]), variant="fast", batch=1, list_cap=-1)
+    assert np.array_equal(perm.numpy(), g["order"]) and np.array_equal(sizes.numpy(), g["group_sizes"])
+
+
+def test_fast_loi_is_a_permutation_independent_of_the_thread_count():
+    for gen, args in ((graphs.community_graph, (60000, 125000)), (graphs.powerlaw_graph, (9000, 150000))):
+        rp, col = gen(*args, seed=5)[:2]
+        N = len(rp) - 1
+        base = None
+        for threads in (1, 2, 5):
+            perm, sizes = hcspmm.loi_reorder(_t(rp), _t(col), variant="fast", threads=threads)
+            assert np.array_equal(np.sort(perm.numpy()), np.arange(N))
+            assert int(sizes.sum()) == int((np.diff(rp) > 0).sum()) and sizes.min() >= 1 and sizes.max() <= 16
+            if base is None:
+                base = perm
+            assert torch.equal(base, perm), threads
+        # an explicit small batch and cap: another permutation, just as deterministic
+        a = hcspmm.loi_reorder(_t(rp), _t(col), variant="fast", batch=7, list_cap=5, threads=1)[0]
+        b = hcspmm.loi_reorder(_t(rp), _t(col), variant="fast", batch=7, list_cap=5, threads=4)[0]
+        assert torch.equal(a, b) and np.array_equal(np.sort(a.numpy()), np.arange(N))
+
+
+def test_fast_loi_recovers_planted_communities():
+    """community_graph hides groups of 8-40 rows sharing a column pool behind shuffled vertex ids; after the relaxed reorder most
+    16-row windows must again come from one or two planted groups, about as many as after the exact reorder."""
+    rp, col, grp = graphs.community_graph(80000, 167000, seed=9)
+    N = len(rp) - 1
+
+    def pure_windows(perm):
+        w = grp[np.asarray(perm)][: N // 16 * 16].reshape(-1, 16)
+        return float(np.mean([len(np.unique(r)) <= 2 for r in w]))
+    assert pure_windows(np.arange(N)) < 0.01
+    fast = pure_windows(hcspmm.loi_reorder(_t(rp), _t(col), variant="fast")[0].numpy())
+    exact = pure_windows(hcspmm.loi_reorder(_t(rp), _t(col))[0].numpy())
+    assert fast > 0.6 and fast > exact - 0.05, (fast, exact)
+    # and the classifier sees it: windows on the dense-tile path before / after
+    before = int(_pre(rp, col)[3].sum())
+    rpr, colr = hcspmm.apply_permutation(_t(rp), _t(col), hcspmm.loi_reorder(_t(rp), _t(col), variant="fast")[0])
+    after = int(_pre(rpr.numpy(), colr.numpy())[3].sum())
+    assert before < 0.02 * (N // 16) and after > 0.8 * (N // 16), (before, after)
+
+
+def test_fast_loi_refuses_malformed_graphs(capi):
+    rp, col = graphs.powerlaw_graph(5000, 30000, seed=2)
+    bad = col.copy()
+    bad[17] = 5000
+    with pytest.raises(RuntimeError):
+        hcspmm.loi_reorder(_t(rp), _t(bad), variant="fast")
+    rp_bad = rp.copy()
+    rp_bad[10] = rp_bad[11] + 1
+    with pytest.raises(RuntimeError):
+        hcspmm.loi_reorder(_t(rp_bad), _t(col), variant="fast")
+    with pytest.raises(RuntimeError):
+        hcspmm.loi_reorder(_t(rp), _t(col), variant="fast", batch=-1)
+    perm, sizes = hcspmm.loi_reorder(_t(np.zeros(1, np.int32)), _t(np.zeros(0, np.int32)), variant="fast")
+    assert perm.numel() == 0 and sizes.numel() == 0
+
+
+def test_apply_permutation_parallel_path_matches_scipy():
+    import scipy.sparse as sp
+    rp, col = graphs.powerlaw_graph(30000, 400000, seed=8)  # enough entries for several host threads
+    N = len(rp) - 1
+    p = np.random.default_rng(1).permutation(N).astype(np.int32)
+    rp2, col2 = hcspmm.apply_permutation(_t(rp), _t(col), _t(p))
+    A = sp.csr_matrix((np.ones(len(col), np.int8), col, rp), shape=(N, N))
+    B = A[p][:, p].tocsr()
+    B.sort_indices()
+    assert np.array_equal(rp2.numpy(), B.indptr) and np.array_equal(col2.numpy(), B.indices)
+
+
 def test_apply_permutation_is_a_graph_isomorphism():
     import scipy.sparse as sp
     rp, col = graphs.powerlaw_graph(700, 5000, seed=6)

@@ -9,6 +9,7 @@
 // per-group N-bit bitmap (LOI.cpp:695, O(N^2/16) overall) and its re-sorted column vector
 // (LOI.cpp:71), and there is no static 18 269 000-entry table (LOI.cpp:96).
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <thread>
 #include <vector>
@@ -336,24 +337,55 @@ extern "C" int hcspmm_apply_permutation(const int32_t* rowptr, const int32_t* co
   if (N < 0 || E < 0 || !rowptr || !rowptr_out || (N > 0 && !perm) || (E > 0 && (!col || !col_out)))
     return HCSPMM_EINVAL;
   if (!hcspmm::csr_row_pointers_ok(rowptr, N, E)) return HCSPMM_EINVAL;
-  for (int64_t e = 0; e < E; ++e)
-    if (col[e] < 0 || col[e] >= N) return HCSPMM_EINVAL;
-  std::vector<int32_t> inv((size_t)N, -1);
-  for (int64_t i = 0; i < N; ++i) {
-    const int32_t old = perm[i];
-    if (old < 0 || old >= N || inv[(size_t)old] != -1) return HCSPMM_EINVAL;
-    inv[(size_t)old] = (int32_t)i;
-  }
-  rowptr_out[0] = 0;
-  for (int64_t i = 0; i < N; ++i) rowptr_out[i + 1] = rowptr_out[i] + (rowptr[perm[i] + 1] - rowptr[perm[i]]);
-  // new rows are independent: contiguous ranges of them, balanced by entries, one per host thread
+  // every pass below is a loop over independent vertices or entries, cut into contiguous ranges for the host threads (on the
+  // RD-sized graph the sequential checks and the inverse permutation were most of the call)
   const int T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(16, hcspmm::host_threads()), E / 65536));
+  auto parallel = [&](int64_t n, auto&& body) {  // body(begin, end)
+    if (T == 1 || n < 4096) {
+      body((int64_t)0, n);
+      return;
+    }
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back([&, t] { body(n * t / T, n * (t + 1) / T); });
+    for (auto& x : th) x.join();
+  };
+  std::atomic<int> bad{0};
+  parallel(E, [&](int64_t a, int64_t b) {
+    for (int64_t e = a; e < b; ++e)
+      if (col[e] < 0 || col[e] >= N) bad.store(1, std::memory_order_relaxed);
+  });
+  if (bad.load()) return HCSPMM_EINVAL;
+  std::vector<int32_t> inv((size_t)N);
+  parallel(N, [&](int64_t a, int64_t b) {
+    for (int64_t i = a; i < b; ++i) inv[(size_t)i] = -1;
+  });
+  parallel(N, [&](int64_t a, int64_t b) {
+    for (int64_t i = a; i < b; ++i) {
+      const int32_t old = perm[i];
+      if (old < 0 || old >= N) {
+        bad.store(1, std::memory_order_relaxed);
+        continue;
+      }
+      __atomic_store_n(&inv[(size_t)old], (int32_t)i, __ATOMIC_RELAXED);
+    }
+  });
+  // a permutation iff every old id was named, i.e. iff nothing is left at -1 (an id named twice leaves another one unnamed)
+  parallel(N, [&](int64_t a, int64_t b) {
+    for (int64_t i = a; i < b; ++i) {
+      if (inv[(size_t)i] < 0) bad.store(1, std::memory_order_relaxed);
+      if (!bad.load(std::memory_order_relaxed)) rowptr_out[i + 1] = rowptr[perm[i] + 1] - rowptr[perm[i]];  // (degrees first, summed below)
+    }
+  });
+  if (bad.load()) return HCSPMM_EINVAL;
+  rowptr_out[0] = 0;
+  for (int64_t i = 0; i < N; ++i) rowptr_out[i + 1] += rowptr_out[i];
+  // new rows, in contiguous ranges balanced by entries
   auto fill_rows = [&](int64_t i0, int64_t i1) {
     for (int64_t i = i0; i < i1; ++i) {
       const int32_t old = perm[i];
       int32_t o = rowptr_out[i];
       for (int32_t e = rowptr[old]; e < rowptr[old + 1]; ++e) col_out[o++] = inv[(size_t)col[e]];
-      std::sort(col_out + rowptr_out[i], col_out + o);
+      if (o - rowptr_out[i] > 1) std::sort(col_out + rowptr_out[i], col_out + o);
     }
   };
   if (T == 1) {

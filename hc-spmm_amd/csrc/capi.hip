@@ -25,20 +25,22 @@ inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_
 
 inline int elem_bytes(int dtype) { return dtype == HCSPMM_DTYPE_F32 ? 4 : 2; }
 
-// widest per-lane access (in elements) the operands allow; the fp32 workspace is read 4*vec bytes at a time
+// Per-lane access width (in elements).  fp32: 16 bytes per lane for every embedding width of at least 4 columns, whatever
+// the row strides and base addresses are -- the kernels address fp32 vectors with element alignment and move a lane whose
+// columns would run past the row back onto the row's last four (spmm_impl.h MemF32 / lane_col) -- 8 bytes for D = 2, 3
+// and single elements for D = 1.  16-bit features keep the divisibility / alignment rule (8, 4 or 1 elements per lane).
 int pick_vec(int dtype, int D, int64_t ldx, int64_t ldz, const void* X, const void* Z, const void* ws) {
+  if (dtype == HCSPMM_DTYPE_F32) return D >= 4 ? 4 : D >= 2 ? 2 : 1;
   const int64_t all = (int64_t)D | ldx | ldz;
   const size_t eb = (size_t)elem_bytes(dtype);
-  for (int v = (dtype == HCSPMM_DTYPE_F32 ? 4 : 8); v > 1; v >>= 1) {
-    if (dtype != HCSPMM_DTYPE_F32 && v == 2) continue;  // 16-bit builds: 8, 4 or 1 elements per lane
+  for (int v = 8; v > 2; v >>= 1)
     if (all % v == 0 && aligned(X, v * eb) && aligned(Z, v * eb) && (!ws || aligned(ws, 4 * (size_t)v))) return v;
-  }
   return 1;
 }
 
 // the access width wide_choice assumes (from the embedding width alone, so that callers can ask ahead of a launch)
 inline int nominal_vec(int dtype, int D) {
-  if (dtype == HCSPMM_DTYPE_F32) return (D % 4 == 0) ? 4 : (D % 2 == 0) ? 2 : 1;
+  if (dtype == HCSPMM_DTYPE_F32) return D >= 4 ? 4 : D >= 2 ? 2 : 1;
   return (D % 8 == 0) ? 8 : (D % 4 == 0) ? 4 : 1;
 }
 }  // namespace

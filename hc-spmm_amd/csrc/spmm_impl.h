@@ -96,6 +96,17 @@ __device__ __forceinline__ void rset(u32x4& v, int i, unsigned w) { v[i] = w; }
 __device__ __forceinline__ void rset(u32x2& v, int i, unsigned w) { v[i] = w; }
 __device__ __forceinline__ void rset(unsigned& v, int, unsigned w) { v = w; }
 
+// fp32 vectors as they are addressed in memory: ELEMENT-aligned.  gfx950's global_load / global_store_dwordx4 need dword
+// alignment only, and saying so lets one 16-byte-per-lane build serve every embedding width of at least 4 columns: a lane
+// whose 4 columns would run past the row is moved back to the row's last 4 (lane_col), so it overlaps its neighbour --
+// both then hold the same sums of the same rows in the same order and store the same bits twice.  The reference packs
+// the remainder columns of such widths into spare warp lanes instead (hybrid_all_kernel.cu:996-1036; paper Table III).
+template <int VEC> struct MemF32 { typedef float type __attribute__((ext_vector_type(VEC), aligned(4))); };
+template <> struct MemF32<1> { typedef float type; };
+
+// first of the VEC feature columns a lane covers, given the aligned position c < cend of its slot in [.., cend)
+template <int VEC> __device__ __forceinline__ int lane_col(int c, int cend) { return VEC == 1 ? c : min(c, cend - VEC); }
+
 template <typename E, int VEC> struct Lane {
   typedef typename E::T T;
   typedef typename RawT<E, VEC>::type raw_t;
@@ -105,7 +116,11 @@ template <typename E, int VEC> struct Lane {
     __builtin_memset(&z, 0, sizeof(z));
     return z;
   }
-  static __device__ __forceinline__ raw_t load(const T* p) { return *reinterpret_cast<const raw_t*>(p); }
+  static __device__ __forceinline__ raw_t load(const T* p) {
+    if constexpr (sizeof(T) == 4) return *reinterpret_cast<const typename MemF32<VEC>::type*>(p);
+    else return *reinterpret_cast<const raw_t*>(p);
+  }
+  static __device__ __forceinline__ acc_t load_partial(const float* p) { return *reinterpret_cast<const typename MemF32<VEC>::type*>(p); }
   // element q of a loaded vector, widened (exact)
   static __device__ __forceinline__ float elem(const raw_t& v, int q) {
     if constexpr (sizeof(T) == 4) return aget(v, q);
@@ -135,10 +150,11 @@ template <typename E, int VEC> struct Lane {
   }
   // Z rows are written once and not re-read by this launch: non-temporal stores (0-5 %, profiles/r01/ab_nt_store.log)
   static __device__ __forceinline__ void store(T* p, const acc_t& acc) {
-    __builtin_nontemporal_store(pack(acc), reinterpret_cast<raw_t*>(p));
+    if constexpr (sizeof(T) == 4) __builtin_nontemporal_store(pack(acc), reinterpret_cast<typename MemF32<VEC>::type*>(p));
+    else __builtin_nontemporal_store(pack(acc), reinterpret_cast<raw_t*>(p));
   }
   static __device__ __forceinline__ void store_partial(float* p, const acc_t& acc) {
-    __builtin_nontemporal_store(acc, reinterpret_cast<acc_t*>(p));
+    __builtin_nontemporal_store(acc, reinterpret_cast<typename MemF32<VEC>::type*>(p));
   }
 };
 
@@ -233,9 +249,9 @@ __device__ __forceinline__ void sparse_task(const typename E::T* __restrict__ X,
   nmax = __builtin_amdgcn_readfirstlane(nmax);
 
   for (int pbase = c0; pbase < cend; pbase += L * VEC) {  // feature columns [c0, cend) of the rows
-    const int c = pbase + s * VEC;
-    const bool cok = c < cend;
-    const int csafe = cok ? c : 0;
+    const bool cok = pbase + s * VEC < cend;
+    const int c = cok ? lane_col<VEC>(pbase + s * VEC, cend) : 0;
+    const int csafe = c;
     acc_t acc = azero<VEC>();
     int next = (pos < n) ? col[e0 + pos] : -1;
     for (int base = 0; base < nmax; base += STRIDE) {
@@ -308,9 +324,9 @@ __device__ __forceinline__ void tiny_tasks(const PlanArgs& a, int first, int c0,
   any1 = __builtin_amdgcn_ballot_w64(any1) != 0;  // wave-uniform: a wave inside the 0- or 1-entry class issues
   any2 = __builtin_amdgcn_ballot_w64(any2) != 0;  // no loads for the absent entries
   for (int pbase = c0; pbase < cend; pbase += L * VEC) {
-    const int c = pbase + s * VEC;
-    const bool cok = c < cend;
-    const int csafe = cok ? c : 0;
+    const bool cok = pbase + s * VEC < cend;
+    const int c = cok ? lane_col<VEC>(pbase + s * VEC, cend) : 0;
+    const int csafe = c;
     typename Ln::raw_t v0[T], v1[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) v0[t] = v1[t] = Ln::zero();
@@ -413,9 +429,9 @@ __device__ __forceinline__ void dense_unit(const typename E::T* __restrict__ X, 
                                            const int* __restrict__ U, cu64_p masks, int K4, int window, int panel,
                                            int N, int D, size_t ldx, size_t ldz, int lane) {
   const int kq = lane >> 4, j = lane & 15;
-  const int c = panel * 16 * VEC + j * VEC;
-  const bool cok = c < D;
-  const int csafe = cok ? c : 0;
+  const bool cok = panel * 16 * VEC + j * VEC < D;
+  const int c = cok ? lane_col<VEC>(panel * 16 * VEC + j * VEC, D) : 0;
+  const int csafe = c;
   f32x4 acc[VEC];
 #pragma unroll
   for (int q = 0; q < VEC; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -513,9 +529,9 @@ __device__ __forceinline__ void dense_compact_unit(const typename E::T* __restri
   const int window = rec.template scalar<0>();
   const int K4 = rec.template scalar<1>();
   const int kq = lane >> 4, j = lane & 15;
-  const int c = panel * 16 * VEC + j * VEC;
-  const bool cok = c < D;
-  const int csafe = cok ? c : 0;
+  const bool cok = panel * 16 * VEC + j * VEC < D;
+  const int c = cok ? lane_col<VEC>(panel * 16 * VEC + j * VEC, D) : 0;
+  const int csafe = c;
   f32x4 acc[VEC];
 #pragma unroll
   for (int q = 0; q < VEC; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -836,19 +852,19 @@ __global__ __launch_bounds__(kThreads) void fixup_kernel(PlanArgs a) {
   while (L < slots && L < 64) L <<= 1;  // lanes per row (a.D > 64*VEC: several column passes of 64 lanes)
   const int R = 64 / L, g = lane / L, sl = lane & (L - 1);
   for (int c0 = 0; c0 < a.D; c0 += L * VEC) {
-    const int c = c0 + sl * VEC;
-    const bool cok = c < a.D;
-    const float* p = a.partial + (size_t)s0 * (size_t)a.D + (cok ? c : 0);
+    const bool cok = c0 + sl * VEC < a.D;
+    const int c = cok ? lane_col<VEC>(c0 + sl * VEC, a.D) : 0;
+    const float* p = a.partial + (size_t)s0 * (size_t)a.D + c;
     acc_t acc = azero<VEC>();
     int s = g;
     for (; s + 7 * R < ns; s += 8 * R) {  // eight independent loads in flight per lane
       acc_t v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const acc_t*>(p + (size_t)(s + u * R) * (size_t)a.D);
+      for (int u = 0; u < 8; ++u) v[u] = Lane<F32, VEC>::load_partial(p + (size_t)(s + u * R) * (size_t)a.D);
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc += v[u];
     }
-    for (; s < ns; s += R) acc += *reinterpret_cast<const acc_t*>(p + (size_t)s * (size_t)a.D);
+    for (; s < ns; s += R) acc += Lane<F32, VEC>::load_partial(p + (size_t)s * (size_t)a.D);
     for (int off = L; off < 64; off <<= 1) {
 #pragma unroll
       for (int q = 0; q < VEC; ++q) aset(acc, q, aget(acc, q) + __shfl_xor(aget(acc, q), off, 64));
@@ -923,8 +939,8 @@ __global__ __launch_bounds__(kThreads) void hybrid_window_kernel(WindowArgs a) {
   const int kq = lane >> 4, j = lane & 15;
   for (int pb = 0; pb < n_panels; pb += nwaves) {  // uniform over the workgroup
     const int panel = pb + wave;
-    const int c = panel * 16 * VEC + j * VEC;
-    const bool cok = panel < n_panels && c < a.D;
+    const bool cok = panel < n_panels && panel * 16 * VEC + j * VEC < a.D;
+    const int c = cok ? lane_col<VEC>(panel * 16 * VEC + j * VEC, a.D) : 0;
     f32x4 acc[VEC];
 #pragma unroll
     for (int q = 0; q < VEC; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1009,7 +1025,9 @@ static hipError_t launch_plan_LV(const PlanArgs& a, hipStream_t stream) {
   constexpr int VM = DenseV<VEC>::mid;
   // (16-bit features have no 4-byte-per-lane build: 32 <= D < 64 takes the 8-byte one with half the lanes idle)
   constexpr int kMidCols = (sizeof(typename E::T) == 2 && VM > 1) ? 8 * VM : 16 * VM;
-  b.dense_vec = (a.D >= 16 * VEC) ? VEC : (a.D >= kMidCols ? VM : 1);
+  // (fp32 widths that are not multiples of 16 count as the next one: D = 22 is ONE 32-column panel of 8-byte lanes, 11 busy)
+  const int d_panel = sizeof(typename E::T) == 4 ? (a.D + 15) / 16 * 16 : a.D;
+  b.dense_vec = (d_panel >= 16 * VEC) ? VEC : (d_panel >= kMidCols ? VM : 1);
   b.n_panels = (a.D + 16 * b.dense_vec - 1) / (16 * b.dense_vec);
   constexpr bool kCanFuse = sizeof(typename E::T) == 4 && VEC == 4;
   constexpr int kMinWaves = sizeof(typename E::T) == 4 ? HCSPMM_MIN_WAVES_PER_SIMD : HCSPMM_MIN_WAVES_H16;

@@ -130,7 +130,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("name,gen,split_free", CASES, ids=[c[0] for c in CASES])
-@pytest.mark.parametrize("D", [32, 128, 256, 16, 22, 7, 96, 1, 300, 1000])
+@pytest.mark.parametrize("D", [32, 128, 256, 16, 22, 7, 96, 1, 300, 1000, 2, 3, 5, 6, 33, 70])
 def test_forward_parity_planned(oracle_mod, dev, fe, name, gen, split_free, D):
     rp, col = gen()
     g = Graph(rp, col, dev, fe=fe)
@@ -140,6 +140,34 @@ def test_forward_parity_planned(oracle_mod, dev, fe, name, gen, split_free, D):
     Xi = np.tile((np.arange(g.N, dtype=np.float32) % 4093)[:, None], (1, D))
     Zi = g.forward(_t(Xi, dev)).cpu().numpy()
     assert np.array_equal(Zi, oracle_mod.spmm_f32(rp, col, Xi))
+
+
+@pytest.mark.parametrize("name,gen,split_free", CASES[:4], ids=[c[0] for c in CASES[:4]])
+@pytest.mark.parametrize("D,pad,off", [(22, 0, 0), (22, 3, 1), (32, 5, 3), (7, 2, 1), (64, 1, 1), (130, 7, 2), (5, 0, 0), (4, 1, 1)])
+def test_forward_parity_on_views_off_the_16_byte_grid(oracle_mod, dev, name, gen, split_free, D, pad, off):
+    """fp32 rows are gathered 16 bytes per lane whatever the width, row stride and base address (element-aligned vectors; a lane
+    that would run past the row is moved back onto its last four columns): X and Z as column slices of wider matrices that
+    start `off` floats into a row of D + pad floats, both kernels (planned and plan-free), same bits as the contiguous call."""
+    import hcspmm
+    rp, col = gen()
+    g = Graph(rp, col, dev)
+    X = np.random.default_rng(D + off).standard_normal((g.N, D)).astype(np.float32)
+    Xd = _t(X, dev)
+    want = g.forward(Xd)
+    _check(oracle_mod, g, X, want)
+    Xw = torch.full((g.N, D + pad + off), float("nan"), device=dev)
+    Zw = torch.full((g.N, D + pad + off), -7.0, device=dev)
+    Xv, Zv = Xw[:, off:off + D], Zw[:, off:off + D]
+    Xv.copy_(Xd)
+    for row_nzr in (g.row_nzr, torch.zeros(1, dtype=torch.int32, device=dev)):
+        Zv.fill_(-7.0)
+        hcspmm.forward_into(Xv, Zv, g.rp_d, g.col_d, g.bp, g.e2c, g.e2r, g.ht, row_nzr, g.col_nzr)
+        torch.cuda.synchronize()
+        if row_nzr is g.row_nzr:
+            assert torch.equal(Zv, want)
+        else:
+            _check(oracle_mod, g, X, Zv.contiguous())
+        assert bool((Zw[:, :off] == -7.0).all()) and bool((Zw[:, off + D:] == -7.0).all())  # nothing written outside the slice
 
 
 @pytest.mark.parametrize("name,gen,split_free", CASES[:4], ids=[c[0] for c in CASES[:4]])

@@ -7,7 +7,7 @@ for w in $WORKLOADS; do
   wl=${w%%:*}; dim=""; [ "$w" != "$wl" ] && dim="--dim ${w##*:}"
   for v in $VARIANTS; do
     name=${v%%=*}; rest=${v#*=}; envs=${rest%%:*}; lib=""; [ "$rest" != "$envs" ] && lib=${rest##*:}
-    out=$(env ${envs:+$envs} ${lib:+HCSPMM_LIB=$PWD/$lib} python3 bench.py --workload $wl $dim --steps $STEPS --warmup 10 --no-sweep --no-pmc --no-cpu-baseline 2>/dev/null)
+    out=$(env ${envs:+$envs} ${lib:+HCSPMM_LIB=$PWD/$lib} python3 bench.py --workload $wl $dim --steps $STEPS --warmup 10 --no-sweep --no-pmc --no-cpu-baseline --frontend ctypes 2>/dev/null)
     python3 - "$w" "$name" <<PY
 import json,sys
 try:

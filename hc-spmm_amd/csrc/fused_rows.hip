@@ -250,21 +250,38 @@ __device__ __forceinline__ void tile_mac(const float* __restrict__ tile, const f
   }
 }
 
+// Hreal = the operator's hidden width; 16*HT when it is a multiple of 16, else the staged weights carry zero columns up to
+// 16*HT and the stores are masked (the update kernel's PAD form, update_kernels.hip: same chain, same bits in the real columns)
 template <int HT>
-__device__ __forceinline__ void tile_store(const int* __restrict__ trow, const f32x4 (&oacc)[HT], float* __restrict__ out, int lane) {
+__device__ __forceinline__ void tile_store(const int* __restrict__ trow, const f32x4 (&oacc)[HT], float* __restrict__ out, int lane,
+                                           int Hreal) {
   constexpr int H = 16 * HT;
   const int i = lane & 15, kq = lane >> 4;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int orow = trow[4 * kq + r];
     if (orow >= 0) {
-      float* o = out + (size_t)orow * (size_t)H + HT * i;
+      float* o = out + (size_t)orow * (size_t)Hreal + HT * i;
+      if (Hreal != H) {
+        // pieces that do not fill 16-byte units: plain (cached) stores, so that the L2 assembles whole lines before they leave
+        if constexpr (HT % 2 == 0) {
+          if ((Hreal & 1) == 0) {
+#pragma unroll
+            for (int t = 0; t < HT; t += 2)
+              if (HT * i + t < Hreal) *reinterpret_cast<typename MemF32<2>::type*>(o + t) = typename AccT<2>::type{oacc[t][r], oacc[t + 1][r]};
+            continue;
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < HT; ++t)
+          if (HT * i + t < Hreal) o[t] = oacc[t][r];
+        continue;
+      }
       // `out` is written once and not read by this operator: non-temporal stores (+4 ... +9 % on the whole call)
       if constexpr (HT == 4) {
-        __builtin_nontemporal_store(f32x4{oacc[0][r], oacc[1][r], oacc[2][r], oacc[3][r]}, reinterpret_cast<f32x4*>(o));
+        __builtin_nontemporal_store(f32x4{oacc[0][r], oacc[1][r], oacc[2][r], oacc[3][r]}, reinterpret_cast<typename MemF32<4>::type*>(o));
       } else if constexpr (HT == 2) {
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        __builtin_nontemporal_store(f32x2{oacc[0][r], oacc[1][r]}, reinterpret_cast<f32x2*>(o));
+        __builtin_nontemporal_store(typename AccT<2>::type{oacc[0][r], oacc[1][r]}, reinterpret_cast<typename MemF32<2>::type*>(o));
       } else {
         __builtin_nontemporal_store(oacc[0][r], o);
       }
@@ -299,7 +316,7 @@ __global__ __launch_bounds__(64 * WV, (KIND == 1 && WV == 4) ? HCSPMM_ROWS_MIN_W
   int* trow = reinterpret_cast<int*>(tile + 16 * TS);
   for (int i = threadIdx.x; i < a.D * H; i += 64 * WV) {
     const int k = i / H, h = i - k * H;
-    s_w[k * HS + h] = a.W[(long long)k * a.w_ldr + (long long)h * a.w_ldc];
+    s_w[k * HS + h] = h < a.H ? a.W[(long long)k * a.w_ldr + (long long)h * a.w_ldc] : 0.0f;  // (a.H < H: zero columns)
   }
   __syncthreads();
   const int4* tasks = reinterpret_cast<const int4*>(a.plan + a.off_tasks);
@@ -324,7 +341,7 @@ __global__ __launch_bounds__(64 * WV, (KIND == 1 && WV == 4) ? HCSPMM_ROWS_MIN_W
 #pragma unroll
       for (int t = 0; t < HT; ++t) oacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       tile_mac<HT>(tile, s_w, TS, a.D, lane, oacc);
-      tile_store<HT>(trow, oacc, a.out, lane);
+      tile_store<HT>(trow, oacc, a.out, lane, a.H);
       wave_lds_fence();  // the next tile's writes stay behind these reads
     } else {
       f32x4 oacc[HT];
@@ -347,7 +364,7 @@ __global__ __launch_bounds__(64 * WV, (KIND == 1 && WV == 4) ? HCSPMM_ROWS_MIN_W
         tile_mac<HT>(tile, s_w + kbase * HS, TS, kcols, lane, oacc);
         wave_lds_fence();  // the next chunk's writes stay behind these reads
       }
-      tile_store<HT>(trow, oacc, a.out, lane);
+      tile_store<HT>(trow, oacc, a.out, lane, a.H);
     }
   }
 }
@@ -357,13 +374,16 @@ static inline int tiles_chunk(int D) { return (D > 64 && D % 64 == 0) ? 64 : D; 
 static inline int tiles_waves(int D) { return tiles_chunk(D) < D ? 8 : kWaves; }
 static inline int tiles_stride(int D) { return (tiles_chunk(D) < D ? 64 : D) + 4; }  // (dense panels of a chunked launch are 64 wide)
 
+static inline int tiles_ht(int H) { return (H + 15) / 16; }  // output tiles of 16 columns; widths in between are zero-padded
 size_t fused_tiles_lds_bytes(int D, int H) {
-  return ((size_t)D * rows_w_stride(H) + (size_t)tiles_waves(D) * (16 * tiles_stride(D) + 16)) * sizeof(float);
+  return ((size_t)D * rows_w_stride(16 * tiles_ht(H)) + (size_t)tiles_waves(D) * (16 * tiles_stride(D) + 16)) * sizeof(float);
 }
 
-// shapes the row-tile form serves: fp32 rows of 16-byte pieces, one lane group of at most 32 lanes per row, H = 16, 32 or 64
+// shapes the row-tile form serves: fp32 rows of 16-byte pieces, one lane group of at most 32 lanes per row, one, two or four
+// output tiles (H <= 32 or 49 ... 64: the reference's default 22 classes pad to 32, as its own fused kernels pad to their
+// tile, hybrid_all_kernel.cu:2748)
 bool fused_tiles_supported(int D, int H) {
-  return D % 16 == 0 && D >= 32 && D <= 128 && (H == 16 || H == 32 || H == 64) && fused_tiles_lds_bytes(D, H) <= 64 * 1024;
+  return D % 16 == 0 && D >= 32 && D <= 128 && H >= 1 && H <= 64 && tiles_ht(H) != 3 && fused_tiles_lds_bytes(D, H) <= 64 * 1024;
 }
 
 // workgroups the chip holds at once (persistent launch: more than that would queue behind whole strided loops).  Asked once per
@@ -419,10 +439,10 @@ static hipError_t launch_tiles_LHD(TilesArgs ta, hipStream_t stream) {
 
 template <int L, int DV, int KIND, int WV>
 static hipError_t launch_tiles_LDK(const TilesArgs& ta, hipStream_t stream) {
-  switch (ta.p.H) {
-    case 16: return launch_tiles_LHD<L, 1, DV, KIND, WV>(ta, stream);
-    case 32: return launch_tiles_LHD<L, 2, DV, KIND, WV>(ta, stream);
-    case 64: return launch_tiles_LHD<L, 4, DV, KIND, WV>(ta, stream);
+  switch (tiles_ht(ta.p.H)) {
+    case 1: return launch_tiles_LHD<L, 1, DV, KIND, WV>(ta, stream);
+    case 2: return launch_tiles_LHD<L, 2, DV, KIND, WV>(ta, stream);
+    case 4: return launch_tiles_LHD<L, 4, DV, KIND, WV>(ta, stream);
     default: return hipErrorInvalidValue;
   }
 }

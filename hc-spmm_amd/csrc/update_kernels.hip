@@ -189,7 +189,7 @@ __global__ __launch_bounds__(kUpdWaves * 64) void dense_update_stream_kernel(con
 template <int T>
 __global__ __launch_bounds__(kUpdWaves * 64) void dense_update_rows_kernel(const float* __restrict__ in,
                                                                            const float* __restrict__ W, long long ldr,
-                                                                           long long ldc, float* __restrict__ out, int D,
+                                                                           long long ldc, float* __restrict__ out, int D, int Hreal,
                                                                            const int* __restrict__ plan, int off_tasks,
                                                                            int n_wide, int off_fixups, int n_split_rows,
                                                                            int off_slice_tasks, int n_slice_tasks) {
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(kUpdWaves * 64) void dense_update_rows_kernel(const
   constexpr int HS = H + 4;
   for (int i = threadIdx.x; i < D * H; i += kUpdWaves * 64) {
     const int k = i / H, h = i - k * H;
-    s_w[k * HS + h] = W[(long long)k * ldr + (long long)h * ldc];
+    s_w[k * HS + h] = h < Hreal ? W[(long long)k * ldr + (long long)h * ldc] : 0.0f;  // (Hreal < 16*T: zero columns, masked stores)
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -251,23 +251,24 @@ __global__ __launch_bounds__(kUpdWaves * 64) void dense_update_rows_kernel(const
     for (int r = 0; r < 4; ++r) {
       const int orow = __shfl(row, 4 * kq + r, 64);
       if (orow >= 0) {
-        float* o = out + (size_t)orow * (size_t)H + T * i;
+        float* o = out + (size_t)orow * (size_t)Hreal + T * i;
 #pragma unroll
-        for (int t = 0; t < T; ++t) o[t] = acc[t][r];
+        for (int t = 0; t < T; ++t)
+          if (T * i + t < Hreal) o[t] = acc[t][r];
       }
     }
   }
 }
 
 template <int T>
-static hipError_t launch_rows(const float* in, const float* W, long long ldr, long long ldc, float* out, int D,
+static hipError_t launch_rows(const float* in, const float* W, long long ldr, long long ldc, float* out, int D, int H,
                               const int* plan, int off_tasks, int n_wide, int off_fixups, int n_split_rows,
                               int off_slice_tasks, int n_slice_tasks, hipStream_t stream) {
   const size_t lds = (size_t)D * (16 * T + 4) * sizeof(float);
   const long long n_tiles = ((long long)n_wide + n_split_rows + n_slice_tasks + 15) / 16;
   int grid = (int)((n_tiles + kUpdWaves - 1) / kUpdWaves);
   if (grid > 1024) grid = 1024;
-  hipLaunchKernelGGL((dense_update_rows_kernel<T>), dim3(grid), dim3(kUpdWaves * 64), lds, stream, in, W, ldr, ldc, out, D,
+  hipLaunchKernelGGL((dense_update_rows_kernel<T>), dim3(grid), dim3(kUpdWaves * 64), lds, stream, in, W, ldr, ldc, out, D, H,
                      plan, off_tasks, n_wide, off_fixups, n_split_rows, off_slice_tasks, n_slice_tasks);
   return hipGetLastError();
 }
@@ -491,11 +492,12 @@ hipError_t launch_dense_update_leftover(const float* in, const float* W, long lo
                                         int D, int H, const int* plan, int off_tasks, int n_wide, int off_fixups,
                                         int n_split_rows, int off_slice_tasks, int n_slice_tasks, hipStream_t stream) {
   if (N <= 0 || (long long)n_wide + n_split_rows + n_slice_tasks <= 0) return hipSuccess;
-  if (!dense_update_streams(in, out, D, H) || (H != 16 && H != 32 && H != 64)) return hipErrorInvalidValue;
+  const int T = (H + 15) / 16;  // output tiles; a width in between is zero-padded to the tile (the row-tile form's shapes)
+  if (D % 16 != 0 || D > 128 || H < 1 || H > 64 || T == 3 || ((uintptr_t)in & 15) != 0) return hipErrorInvalidValue;
 #define HCSPMM_ROWS_CASE(T_) \
-  return launch_rows<T_>(in, W, ldr, ldc, out, D, plan, off_tasks, n_wide, off_fixups, n_split_rows, off_slice_tasks, n_slice_tasks, stream);
-  if (H == 64) { HCSPMM_ROWS_CASE(4) }
-  if (H == 32) { HCSPMM_ROWS_CASE(2) }
+  return launch_rows<T_>(in, W, ldr, ldc, out, D, H, plan, off_tasks, n_wide, off_fixups, n_split_rows, off_slice_tasks, n_slice_tasks, stream);
+  if (T == 4) { HCSPMM_ROWS_CASE(4) }
+  if (T == 2) { HCSPMM_ROWS_CASE(2) }
   HCSPMM_ROWS_CASE(1)
 #undef HCSPMM_ROWS_CASE
 }

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "hcspmm_dist.h"
+#include "host_util.h"
 
 namespace {
 thread_local int g_last_error = 0;
@@ -34,6 +35,7 @@ extern "C" int hcspmm_dist_last_error(void) { return g_last_error; }
 // hcspmm/sharded.py partition_rows, restated: cut where (entries + rows before a window boundary) crosses p / world of the total
 extern "C" int hcspmm_dist_partition_rows(const int32_t* rowptr, int64_t N, int world, int64_t* ranges) {
   if (!rowptr || !ranges || N < 0 || world < 1) return HCSPMM_EINVAL;
+  if (rowptr[N] < 0 || !hcspmm::csr_row_pointers_ok(rowptr, N, rowptr[N])) return HCSPMM_EINVAL;  // start at 0, never decrease
   const int64_t W = (N + HCSPMM_BLK_H - 1) / HCSPMM_BLK_H;
   auto wstart = [&](int64_t w) { return std::min<int64_t>(w * HCSPMM_BLK_H, N); };
   auto cost = [&](int64_t w) { return (int64_t)rowptr[wstart(w)] + wstart(w); };
@@ -61,6 +63,9 @@ extern "C" int hcspmm_dist_partition_rows(const int32_t* rowptr, int64_t N, int 
 extern "C" int hcspmm_dist_extract_block(const int32_t* rowptr, const int32_t* col, int64_t N, int world, const int64_t* ranges,
                                          int rank, int32_t* rp_out, int32_t* col_out, int64_t* pad_rows_out) {
   if (!rowptr || !ranges || !rp_out || N < 0 || world < 1 || rank < 0 || rank >= world) return HCSPMM_EINVAL;
+  // the interface has no entry count of its own: rowptr[N] is it, once the pointers are known to start at 0 and never to
+  // decrease (every [rowptr[r], rowptr[r + 1]) then lies inside the caller's column_index[0, rowptr[N]))
+  if (rowptr[N] < 0 || !hcspmm::csr_row_pointers_ok(rowptr, N, rowptr[N])) return HCSPMM_EINVAL;
   int64_t pad = 0;
   for (int p = 0; p < world; ++p) {
     if (ranges[2 * p] < 0 || ranges[2 * p + 1] < ranges[2 * p] || ranges[2 * p + 1] > N) return HCSPMM_EINVAL;

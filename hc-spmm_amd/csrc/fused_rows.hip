@@ -29,7 +29,6 @@
 #ifndef HCSPMM_TILES_DENSE_B
 #define HCSPMM_TILES_DENSE_B 4
 #endif
-#define HCSPMM_DENSE_B HCSPMM_TILES_DENSE_B
 #include "spmm_impl.h"
 
 namespace hcspmm {
@@ -210,7 +209,7 @@ __device__ __forceinline__ void dense_tile(const PlanArgs& a, int unit, float* _
     const int K4 = dix[2];
     const int* U = a.plan + a.off_dense_pack + dix[1];
     cu64_p masks = (cu64_p)(U + 4 * K4);
-    HCSPMM_TILE_PANELS((dense_chain<F32, DV, false>(X, U, masks, K4, csafe, cok, a.ldx, lane, acc)))
+    HCSPMM_TILE_PANELS((dense_chain<F32, DV, false, HCSPMM_TILES_DENSE_B>(X, U, masks, K4, csafe, cok, a.ldx, lane, acc)))
   } else if (unit < n_reg + a.n_dense_compact2) {
     Rec<2> rec;
     const int* recp = a.plan + a.off_dense_compact2 + (unit - n_reg) * HCSPMM_COMPACT2_WORDS;

@@ -386,7 +386,9 @@ __device__ __forceinline__ f32x4 tile_mfma(float a01, float x, f32x4 acc) {
   else return __builtin_amdgcn_mfma_f32_16x16x4f32(a01, x, acc, 0, 0, 0);
 }
 
-template <typename E, int VEC, bool TR>
+// DB: k-steps per batch at 16 bytes per lane (a template parameter, not the macro itself: fused_rows.hip runs this chain with
+// a smaller batch, and one template with two bodies in two translation units would be an ODR violation)
+template <typename E, int VEC, bool TR, int DB>
 __device__ __forceinline__ void dense_chain(const typename E::T* __restrict__ X, const int* __restrict__ U, cu64_p masks,
                                             int K4, int csafe, bool cok, size_t ldx, int lane, f32x4 (&acc)[VEC]) {
   typedef Lane<E, VEC> Ln;
@@ -395,7 +397,7 @@ __device__ __forceinline__ void dense_chain(const typename E::T* __restrict__ X,
     const int myU = (kb * 4 + lane < K4 * 4) ? U[kb * 4 + lane] : -1;
     const int steps = min(16, K4 - kb);
     // same bytes in flight per lane whatever the panel width
-    constexpr int B = HCSPMM_DENSE_B * 16 / (VEC * (int)sizeof(typename E::T));
+    constexpr int B = DB * 16 / (VEC * (int)sizeof(typename E::T));
     for (int t0 = 0; t0 < steps; t0 += B) {
       // Branch-free batch (see sparse_task): padded columns (U = -1) and steps past the end re-read
       // row 0 and are zeroed by the select; their A tile is zero as well.
@@ -435,7 +437,7 @@ __device__ __forceinline__ void dense_unit(const typename E::T* __restrict__ X, 
   f32x4 acc[VEC];
 #pragma unroll
   for (int q = 0; q < VEC; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-  dense_chain<E, VEC, false>(X, U, masks, K4, csafe, cok, ldx, lane, acc);
+  dense_chain<E, VEC, false, HCSPMM_DENSE_B>(X, U, masks, K4, csafe, cok, ldx, lane, acc);
   if (cok) dense_store<E, VEC>(Z, acc, window, kq, c, N, ldz);
 }
 
@@ -623,7 +625,7 @@ __device__ __forceinline__ void fused_dense_window(const PlanArgs& a, int unit, 
     const int K4 = dix[2];
     const int* U = a.plan + a.off_dense_pack + dix[1];
     cu64_p masks = (cu64_p)(U + 4 * K4);
-    HCSPMM_FUSED_PANELS((dense_chain<F32, DV, true>(X, U, masks, K4, csafe, cok, a.ldx, lane, acc)))
+    HCSPMM_FUSED_PANELS((dense_chain<F32, DV, true, HCSPMM_DENSE_B>(X, U, masks, K4, csafe, cok, a.ldx, lane, acc)))
   } else if (unit < n_reg + a.n_dense_compact2) {
     Rec<2> rec;
     const int* recp = a.plan + a.off_dense_compact2 + (unit - n_reg) * HCSPMM_COMPACT2_WORDS;
@@ -719,6 +721,9 @@ __global__ __launch_bounds__(kThreads, MINW) void hybrid_plan_kernel(PlanArgs a)
       sparse_task<E, L, VEC, true, UNROLL>(X, dz, dp, a.col, __builtin_amdgcn_readfirstlane(t.y),
                                            __builtin_amdgcn_readfirstlane(t.z), a.ldx, c0, cend, lane);
     } else if (bf >= sparse_wgs_pp_ordinary_end(a)) {
+      // (bf >= free_wgs_pp: the workgroups that pad a sliced panel to a multiple of 8 -- with the tiny tasks in their own
+      // launch, tiny_wgs = 0, they would otherwise sum real tiny tasks a second time: same values, wasted work)
+      if (bf >= a.free_wgs_pp) return;
       constexpr int R = 64 / L;
       const int first = a.n_tasks - a.n_tiny + ((bf - sparse_wgs_pp_ordinary_end(a)) * kWaves + wave) * (R * TinyT<L>::value);
       if (first >= a.n_tasks) return;

@@ -82,6 +82,11 @@ __global__ __launch_bounds__(kUpdWaves * 64) void dense_update_kernel(const floa
 // PAD: H is not 16*T -- the staged weights are zero-padded to 16*T columns, the stores masked.  DPAD: D is even but not a
 // multiple of 16 (the reference's default 22 classes as the INPUT width): rows of agg are read in 8-byte pairs, the staged
 // weights zero-padded to whole 16-row chunks.
+// vectors of `out` (and the 8-byte pairs of a DPAD `in`) are addressed with ELEMENT alignment: a caller's output matrix that is
+// only 4-byte aligned, or rows of an odd width, still take one 8- / 16-byte store (gfx950 needs dword alignment only)
+typedef float upd_f32x2 __attribute__((ext_vector_type(2), aligned(4)));
+typedef float upd_f32x4 __attribute__((ext_vector_type(4), aligned(4)));
+
 template <int T, bool PAD, bool DPAD = false>
 __global__ __launch_bounds__(kUpdWaves * 64) void dense_update_stream_kernel(const float* __restrict__ in,
                                                                              const float* __restrict__ W,
@@ -119,12 +124,12 @@ __global__ __launch_bounds__(kUpdWaves * 64) void dense_update_stream_kernel(con
           const int k = k0 + 16 * u + 4 * kq;  // columns k .. k + 3 of this lane's row, as two pairs (D is even)
           const float* ap = in + (size_t)(rok ? row : 0) * (size_t)D + k;
           if (rok && k < D) {
-            const f32x2 lo = *reinterpret_cast<const f32x2*>(ap);
+            const f32x2 lo = *reinterpret_cast<const upd_f32x2*>(ap);
             a[u][0] = lo[0];
             a[u][1] = lo[1];
           }
           if (rok && k + 2 < D) {
-            const f32x2 hi = *reinterpret_cast<const f32x2*>(ap + 2);
+            const f32x2 hi = *reinterpret_cast<const upd_f32x2*>(ap + 2);
             a[u][2] = hi[0];
             a[u][3] = hi[1];
           }
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(kUpdWaves * 64) void dense_update_stream_kernel(con
             if ((Hreal & 1) == 0) {  // 8-byte aligned pairs
 #pragma unroll
               for (int t = 0; t < T; t += 2)
-                if (T * i + t < Hreal) *reinterpret_cast<f32x2*>(o + t) = f32x2{acc[t][r], acc[t + 1][r]};
+                if (T * i + t < Hreal) *reinterpret_cast<upd_f32x2*>(o + t) = f32x2{acc[t][r], acc[t + 1][r]};
               continue;
             }
           }
@@ -169,9 +174,9 @@ __global__ __launch_bounds__(kUpdWaves * 64) void dense_update_stream_kernel(con
             if (T * i + t < Hreal) o[t] = acc[t][r];
         } else if constexpr (T == 2) {
           typedef float f32x2 __attribute__((ext_vector_type(2)));
-          __builtin_nontemporal_store(f32x2{acc[0][r], acc[1][r]}, reinterpret_cast<f32x2*>(o));
+          __builtin_nontemporal_store(f32x2{acc[0][r], acc[1][r]}, reinterpret_cast<upd_f32x2*>(o));
         } else if constexpr (T == 4) {
-          __builtin_nontemporal_store(f32x4{acc[0][r], acc[1][r], acc[2][r], acc[3][r]}, reinterpret_cast<f32x4*>(o));
+          __builtin_nontemporal_store(f32x4{acc[0][r], acc[1][r], acc[2][r], acc[3][r]}, reinterpret_cast<upd_f32x4*>(o));
         } else {
 #pragma unroll
           for (int t = 0; t < T; ++t) __builtin_nontemporal_store(acc[t][r], o + t);

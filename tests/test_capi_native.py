@@ -78,6 +78,16 @@ def test_dist_host_side_matches_the_python_shard():
                                                    rp_out.ctypes.data, col_out.ctypes.data, ctypes.byref(pad)) == 0
                 assert pad.value == g.pad_rows and np.array_equal(rp_out, g.row_pointers)
                 assert np.array_equal(col_out[:len(g.column_index)], g.column_index)
+    # row pointers that decrease or do not start at 0 are refused before a single column id is read (the interface takes no
+    # entry count: rowptr[N] is it)
+    rp, col = cases[2]
+    for broken in (np.concatenate([rp[:10], rp[10:11] + 50, rp[11:]]).astype(np.int32), (rp + 1).astype(np.int32)):
+        ranges = np.zeros(4, np.int64)
+        assert L.hcspmm_dist_partition_rows(broken.ctypes.data, 40, 2, ranges.ctypes.data) != 0
+        ok = np.array([0, 16, 16, 40], np.int64)
+        out_rp, out_col = np.zeros(41, np.int32), np.zeros(len(col) + 64, np.int32)
+        assert L.hcspmm_dist_extract_block(broken.ctypes.data, col.ctypes.data, 40, 2, ok.ctypes.data, 0, out_rp.ctypes.data,
+                                           out_col.ctypes.data, None) != 0
     bad = np.array([0, 16, 8, 40], np.int64)  # ranges that do not tile the rows
     assert L.hcspmm_dist_extract_block(cases[2][0].ctypes.data, cases[2][1].ctypes.data, 40, 2, bad.ctypes.data, 0, None, None, None) != 0
 

@@ -532,6 +532,29 @@ def test_fused_variants(oracle_mod, dev, fe, gname, gen, D, H, form):
     assert np.array_equal(out2.cpu().numpy(), zi) and np.array_equal(out.cpu().numpy(), zi.astype(np.float64) @ Wi.astype(np.float64))
 
 
+@pytest.mark.parametrize("D,H", [(32, 22), (22, 32), (32, 32), (64, 64), (32, 16), (22, 22), (32, 7)])
+def test_fused_final_into_an_output_that_is_only_4_byte_aligned(oracle_mod, dev, D, H):
+    """forward_final_fused writes the caller's `output`: a matrix that starts one float into an allocation (rows of H floats, so
+    neither the base nor the rows sit on the 8- / 16-byte grid) takes the same vector stores with element alignment -- same bits
+    as an aligned output, nothing written outside it."""
+    import hcspmm
+    rp, col = graphs.planted_dense_graph(1500 - 7, seed=14)
+    g = Graph(rp, col, dev)
+    X, W = torch.randn(g.N, D, device=dev), torch.randn(D, H, device=dev)
+    want = hcspmm.forward_fixed32_fused(X, *g.args(), W)[0]
+    for form in (0, 2):
+        args = list(g.args())
+        if form:
+            args[6] = hcspmm.build_plan(g.rp_d, g.col_d, g.bp, g.e2c, g.ht, fuse_in_launch=2, panel_cols=-1)
+        raw = torch.full((g.N * H + 3,), -3.0, device=dev)
+        buf = raw[1:1 + g.N * H].view(g.N, H)
+        assert buf.data_ptr() % 8 == 4
+        out, out2 = hcspmm.forward_final_fused(X, *args, W, buf)
+        torch.cuda.synchronize()
+        assert out.data_ptr() == buf.data_ptr() and torch.equal(buf, want)
+        assert float(raw[0]) == -3.0 and bool((raw[1 + g.N * H:] == -3.0).all())
+
+
 @pytest.mark.parametrize("D,H", [(32, 32), (64, 16), (64, 64), (128, 32), (96, 64)])
 def test_fused_row_tiles_are_automatic_on_million_row_graphs(oracle_mod, dev, fe, D, H):
     """A graph whose aggregate (N x D fp32) is 80 MB or more takes the row-tile form without being asked (out2 is then beyond

@@ -116,26 +116,53 @@ def make_local_block(workload, n_local, e_local, world, rank, seed=3):
     return graphs.powerlaw_block(n_local, n_local * world, e_local, seed=seed, rank=rank)
 
 
-def make_strong_block(workload, world, rank, seed=3, chunks=STRONG_CHUNKS, scale=1):
-    """Rows [rank, rank + 1) * N / world of the strong-scaling graph `workload` (columns global): the concatenation of this
-    rank's chunks.  scale > 1 shrinks the graph (tests).  -> (row_pointers, column_index, n_local, n_total)."""
+def _strong_chunk(job):
+    """One row chunk of a strong-scaling graph (a top-level function: worker processes of make_strong_block import it)."""
+    workload, n_chunk, n_total, e_chunk, seed, c = job
     from hcspmm import graphs
+    if workload == "c5":
+        return graphs.planted_powerlaw_block(n_chunk, n_total, e_chunk, seed=seed, rank=c)
+    return graphs.powerlaw_block(n_chunk, n_total, e_chunk, seed=seed, rank=c)
+
+
+def make_strong_block(workload, world, rank, seed=3, chunks=STRONG_CHUNKS, scale=1, workers=1):
+    """Rows [rank, rank + 1) * N / world of the strong-scaling graph `workload` (columns global): the concatenation of this
+    rank's chunks.  scale > 1 shrinks the graph (tests).  workers > 1: the chunks -- each a function of (seed, chunk id) alone --
+    are generated by that many fresh host processes (spawned, so they never inherit a GPU context).
+    -> (row_pointers, column_index, n_local, n_total)."""
     n_total, e_total, _, _ = STRONG_WORKLOADS[workload]
     if chunks % world != 0:
         raise SystemExit("bench.py: --workload %s splits %d row chunks: --gpus must divide that (1, 2, 4, 8, ...)" % (workload, chunks))
     n_chunk, e_chunk = n_total // chunks // scale // 16 * 16, e_total // chunks // scale
     n_total = n_chunk * chunks
     per = chunks // world
+    jobs = [(workload, n_chunk, n_total, e_chunk, seed, c) for c in range(rank * per, (rank + 1) * per)]
     rps, cols, base = [np.zeros(1, np.int64)], [], 0
-    t_last = time.time()
-    for c in range(rank * per, (rank + 1) * per):
-        if rank == 0 and time.time() - t_last > 30.0:  # the 16 M-node graph takes minutes on one rank: say that the run is alive
-            print("bench.py: generating %s, row chunk %d of %d" % (workload, c - rank * per, per), file=sys.stderr, flush=True)
-            t_last = time.time()
-        if workload == "c5":
-            rp, col = graphs.planted_powerlaw_block(n_chunk, n_total, e_chunk, seed=seed, rank=c)
-        else:
-            rp, col = graphs.powerlaw_block(n_chunk, n_total, e_chunk, seed=seed, rank=c)
+    if workers > 1:
+        # plain child interpreters (not multiprocessing: nothing of this process -- its __main__, its GPU context -- is inherited),
+        # each generating every workers-th chunk into a scratch directory
+        tmp = tempfile.mkdtemp(prefix="hcspmm_chunks_")
+        code = ("import sys, json, numpy as np; sys.path[:0] = %r; import bench\n"
+                "for i, job in enumerate(json.loads(sys.argv[1])):\n"
+                "    if i %% int(sys.argv[3]) == int(sys.argv[2]):\n"
+                "        rp, col = bench._strong_chunk(tuple(job)); np.save('%s/rp_%%d.npy' %% i, rp); np.save('%s/col_%%d.npy' %% i, col)\n"
+                % ([ROOT, os.path.join(ROOT, "hc-spmm_amd")], tmp, tmp))
+        n_proc = min(workers, len(jobs))
+        procs = [subprocess.Popen([sys.executable, "-c", code, json.dumps(jobs), str(w), str(n_proc)]) for w in range(n_proc)]
+        rcs = [p.wait() for p in procs]
+        if any(rcs):
+            shutil.rmtree(tmp, ignore_errors=True)
+            raise RuntimeError("bench.py: a chunk generator exited with %s" % rcs)
+        parts = [(np.load(os.path.join(tmp, "rp_%d.npy" % i)), np.load(os.path.join(tmp, "col_%d.npy" % i))) for i in range(len(jobs))]
+        shutil.rmtree(tmp, ignore_errors=True)
+    else:
+        parts, t_last = [], time.time()
+        for i, job in enumerate(jobs):
+            if rank == 0 and time.time() - t_last > 30.0:  # the 16 M-node graph takes minutes on one rank: say that the run is alive
+                print("bench.py: generating %s, row chunk %d of %d" % (workload, i, per), file=sys.stderr, flush=True)
+                t_last = time.time()
+            parts.append(_strong_chunk(job))
+    for rp, col in parts:
         rps.append(rp[1:].astype(np.int64) + base)
         cols.append(col)
         base += int(rp[-1])

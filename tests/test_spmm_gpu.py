@@ -885,3 +885,17 @@ def test_config5_share_dense_heavy(oracle_mod, dev):
     W = 125000
     assert h.n_dense > 0.6 * W and h.max_dense_k <= 24 and h.n_dense_compact == h.n_dense
     assert h.nnz_dense > 0.4 * len(col) and h.nnz_sparse > 0.4 * len(col)  # both sub-paths carry real work
+
+
+def test_config5_full_size_on_one_gpu(oracle_mod, dev):
+    """BASELINE config 5 at FULL size on ONE GPU (it fits 288 GB): 16 M nodes / 256 M stored entries, dim 128, 70 % of the
+    16-row windows planted groups of 8-24 columns (dense-tile path under the reference's classifier) -- the graph
+    `bench.py --workload c5` times (bench.make_strong_block("c5", 1, 0): 64 row chunks, generated here by 16 spawned host
+    processes).  X and Z are 8.2 GB each, N*D = 2.05e9 > 2^31.  Same size-independent properties as the other full-size tests."""
+    import bench
+    rp, col, n_local, n_total = bench.make_strong_block("c5", 1, 0, workers=16)
+    assert n_local == n_total == 16000000 and abs(len(col) - 256000000) < 256000 and int(col.max()) > 15_990_000
+    h = _full_size_properties(oracle_mod, dev, rp, col, n_total, 128)
+    W = 1000000
+    assert h.n_dense > 0.6 * W and h.max_dense_k <= 24 and h.n_dense_compact == h.n_dense
+    assert h.nnz_dense > 0.4 * len(col) and h.nnz_sparse > 0.4 * len(col) and h.n_slices == 8

@@ -200,11 +200,12 @@ class _Frontend:
 
     def preprocess(self, col_d, rp_d, N, E, W, rule, num_columns):
         if self.name == "extension":
+            before = self.m.get_rule()
             self.m.set_rule(int(rule))
             try:
                 return self.m.preprocess(col_d, rp_d, N, E, W, int(num_columns))
             finally:
-                self.m.set_rule(0)
+                self.m.set_rule(before)
         return self.m.preprocess(col_d, rp_d, N, E, W, rule=rule, num_columns=num_columns)
 
     def header(self, row_nzr):
@@ -232,6 +233,9 @@ PMC_PASSES = {"fetch": ["FETCH_SIZE"], "write": ["WRITE_SIZE"], "l2": ["TCC_HIT_
 
 def case_key(workload, D, dtype="f32", rule=0):
     return "%s_d%d%s%s" % (workload, D, "" if dtype == "f32" else "_" + dtype, "" if not rule else "_r%d" % rule)
+
+
+DEFAULT_RULE = 3  # the library's default classifier: the width-agnostic MI355X refit (hcspmm.default_rule())
 
 
 def mi355x_rule(D):
@@ -631,7 +635,8 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (traffic then comes from profiles/ or is null)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "bf16"],
                     help="feature element type; f32 is the reference's (and BASELINE's) -- the 16-bit variants are the paper's Table VII extension")
-    ap.add_argument("--rule", type=int, default=0, help="window classifier (hcspmm.h: 0 intended, 2 as shipped = all sparse, 3 / 4 MI355X refits)")
+    ap.add_argument("--rule", type=int, default=3, help="window classifier (hcspmm.h): 3 = MI355X refit, width-agnostic (the library's default), 4 = MI355X refit for "
+                                                       "widths >= 64; the reference's: 0 intended, 1 guarded, 2 as shipped = all sparse")
     ap.add_argument("--no-plan", action="store_true", help="use the plan-free (reference-convention) kernel")
     ap.add_argument("--virtual-world", type=int, default=0,
                     help="one-GPU run of ONE rank's local product in a P-GPU job: the row block references columns of "
@@ -723,7 +728,7 @@ def main():
     else:
         rp, col = graph_of(args.workload)
     sweep_plan = [(w, d) for w, d in SWEEP_PLAN if not (w == args.workload and d == D)] if do_sweep else []
-    cases = [(args.workload, D, args.rule)] + [(w, d, 0) for w, d in sweep_plan] + (loi_plan() if do_loi else [])
+    cases = [(args.workload, D, args.rule)] + [(w, d, DEFAULT_RULE) for w, d in sweep_plan] + (loi_plan() if do_loi else [])
     if args.pmc_child and args.cases:
         cases = [(c.split(":")[0], int(c.split(":")[1]), int((c.split(":") + ["0"])[2])) for c in args.cases.split(",")]
     pmc = None
@@ -792,7 +797,7 @@ def main():
             source = ("this run: rocprofv3 --pmc child passes of bench.py on the same graph before the timed region "
                       "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB); seconds per pass (all cases) %s" % json.dumps(pmc["_passes"]))
             extra = {k: pmc[key].get(k) for k in ("fetch_bytes", "write_bytes", "l2_hit_rate", "mfma_util_percent")}
-        elif world == 1 and args.rule == 0 and not args.no_plan:
+        elif world == 1 and args.rule == DEFAULT_RULE and not args.no_plan:
             rec = recorded_profile(key)
             if rec and not rec.get("stale"):
                 traffic = rec.get("traffic_bytes")
@@ -1036,9 +1041,10 @@ def loi_block(fe, dev, args, graph_of, pmc, info):
                                "reorder_alone_percent_of_200_epochs": 100.0 * info.get("reorder_s", float("nan")) / run200,
                                "epochs_to_amortise": cost / max((ep["as shuffled"] - ep["after LOI reorder"]) * 1e-3, 1e-12),
                                "paper": "LOA cost 6.58 % of a 200-epoch run, +8.40 % average (p.13-14, RTX 3090)"}
-        out["default_rule"] = ("preprocess keeps rule 0 (the reference's coefficients): hybrid_type stays bit-identical to the reference's and "
-                               "preprocess is not told the embedding width the refits depend on; HCSPMM.set_rule(3 | 4) / "
-                               "hcspmm.preprocess(rule='mi355x', dim=D) select the refit -- both are timed above")
+        out["default_rule"] = ("preprocess defaults to rule 3, the MI355X refit that holds at every embedding width (never slower than the reference's "
+                               "RTX-3090 coefficients on any workload measured, up to 25 % faster: profiles/r04/ab_classifier_rules.log); "
+                               "hcspmm.preprocess(rule='mi355x', dim=D) / HCSPMM.set_rule(4) pick the wide set for D >= 64; HCSPMM.set_rule(0) / "
+                               "HCSPMM_RULE=0 select the reference's coefficients (hybrid_type then equals the reference's bit for bit) -- both are timed above")
     except Exception as ex:  # never takes the headline down
         out["error"] = str(ex)[:400]
     return out
@@ -1125,8 +1131,8 @@ def sweep(fe, dev, args, plan, graph_of, pmc):
         try:
             rp, col = graph_of(wl)
             gen_s = time.perf_counter() - t0
-            case = run_case(fe, dev, wl, D, rp, col, n_local, 1, 0, vw, steps, warmup, "f32", 0)
-            key = case_key(wl, D)
+            case = run_case(fe, dev, wl, D, rp, col, n_local, 1, 0, vw, steps, warmup, "f32", DEFAULT_RULE)
+            key = case_key(wl, D, "f32", DEFAULT_RULE)
             live = pmc.get(key) if pmc and "error" not in pmc else None
             traffic, src, rec = None, None, None
             if live and live.get("traffic_bytes"):

@@ -42,7 +42,8 @@ def parse_args(argv=None):
     p.add_argument("--graph", action="store_true", help="capture the training step into a HIP graph and replay it")
     # addition: window classifier (hcspmm.h: 0 the reference's intended rule, 2 as shipped, 3 / 4 the MI355X refits
     # for embedding widths below / from 64)
-    p.add_argument("--rule", type=int, default=0, choices=[0, 1, 2, 3, 4], help="window classifier rule")
+    p.add_argument("--rule", type=int, default=-1, choices=[-1, 0, 1, 2, 3, 4],
+                   help="window classifier rule (-1: the module's default, the width-agnostic MI355X refit; 0: the reference's coefficients)")
     # addition: measure the launch-plan variants no size rule predicts (column slices, panel width) on THIS graph and
     # GPU and keep the fastest (hcspmm.tune_plan: a few plan builds and a few hundred launches before the first epoch)
     p.add_argument("--tune", action="store_true", help="tune the launch plan on this graph before training")
@@ -91,7 +92,7 @@ def main(argv=None):
     row_pointers = dataset.row_pointers.to(device)
     output = torch.zeros(num_nodes, args.hidden, device=device)
 
-    if args.rule and hasattr(HCSPMM, "set_rule"):
+    if args.rule >= 0 and hasattr(HCSPMM, "set_rule"):
         HCSPMM.set_rule(args.rule)
     start = time.perf_counter()
     blockPartition, edgeToColumn, edgeToRow, hybrid_type, row_nzr, col_nzr = HCSPMM.preprocess(

@@ -24,20 +24,30 @@ __all__ = [
     "forward_fixed64_fused", "forward_final_fused", "forward_final_fused_64", "forward_GIN_final_fused", "backward",
     "backward_fixed32", "backward_fixed32_fused", "backward_final_fused", "backward_fixed64",
     "backward_fixed64_fused", "backward_final_fused_64", "backward_GIN_final_fused", "loi_reorder",
-    "apply_permutation", "weight_grad", "plan_header", "forward_rect", "forward_into", "wide_threshold", "workspace_bytes", "fused_in_launch", "build_plan", "set_default_rule", "RULE_INTENDED", "RULE_INTENDED_GUARD",
+    "apply_permutation", "weight_grad", "plan_header", "forward_rect", "forward_into", "wide_threshold", "workspace_bytes", "fused_in_launch", "build_plan", "set_default_rule", "default_rule", "RULE_INTENDED", "RULE_INTENDED_GUARD",
     "RULE_AS_SHIPPED", "RULE_MI355X", "RULE_MI355X_WIDE", "mi355x_rule", "tune_plan",
 ]
 
-_DEFAULT_RULE = int(os.environ.get("HCSPMM_RULE", RULE_INTENDED))
+# The window classifier preprocess() uses when the caller names none.  The reference's coefficients (rule 0) were fitted on an
+# RTX 3090 and its paper says they hold only "while the GPU architecture ... remain[s] unchanged" (p.7): the default here is the
+# refit made on MI355X with the reference's own procedure -- the NARROW one (RULE_MI355X), because preprocess is not told the
+# embedding width and that set is never slower than rule 0 at any width (profiles/r04/ab_classifier_rules.log: -1 ... +25 %),
+# while the wide set loses up to 15 % below 64 columns.  preprocess(rule="mi355x", dim=D) picks the set for a known width;
+# HCSPMM_RULE=0 / set_default_rule(RULE_INTENDED) / rule=0 give the reference's hybrid_type bit for bit.
+_DEFAULT_RULE = int(os.environ.get("HCSPMM_RULE", RULE_MI355X))
 _PLAN_PARAMS = PlanParams(int(os.environ.get("HCSPMM_SPLIT_THRESHOLD", 0)), int(os.environ.get("HCSPMM_SEGMENT_LEN", 0)),
                           int(os.environ.get("HCSPMM_FUSE_IN_LAUNCH", 0)))
 
 
 def set_default_rule(rule):
-    """Classifier rule used by preprocess(): RULE_INTENDED (default), _GUARD, _AS_SHIPPED or one of the
-    MI355X refits (mi355x_rule(D))."""
+    """Classifier rule used by preprocess(): RULE_MI355X (default: the width-agnostic MI355X refit), RULE_MI355X_WIDE
+    (mi355x_rule(D) picks between the two), or the reference's RULE_INTENDED, _GUARD, _AS_SHIPPED."""
     global _DEFAULT_RULE
     _DEFAULT_RULE = int(rule)
+
+
+def default_rule():
+    return _DEFAULT_RULE
 
 
 def mi355x_rule(embedding_dim):

@@ -23,7 +23,10 @@ namespace {
   CHECK_CUDA(x);       \
   CHECK_CONTIGUOUS(x)
 
-int g_rule = HCSPMM_RULE_INTENDED;
+// The classifier preprocess uses until set_rule says otherwise: the MI355X refit that holds at every embedding width (the reference's
+// coefficients were fitted on an RTX 3090 and are valid only while the GPU architecture is unchanged, paper p.7; set_rule(0) selects them and
+// gives the reference's hybrid_type bit for bit; profiles/r04/ab_classifier_rules.log has the measurement behind the choice)
+int g_rule = HCSPMM_RULE_MI355X;
 hcspmm_plan_params g_params = {0, 0, 0, 0, 0, 0};
 
 void check_rc(int rc, const char* what) {
@@ -430,7 +433,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("set_rule", [](int rule) {
     TORCH_CHECK(rule >= HCSPMM_RULE_INTENDED && rule <= HCSPMM_RULE_MI355X_WIDE, "unknown rule");
     g_rule = rule;
-  }, "0 = intended classifier (default), 1 = with the size>32 guard, 2 = as shipped (hybrid_all_kernel.cu:262), 3 = MI355X refit");
+  }, "3 = MI355X refit, narrow / width-agnostic (default), 4 = MI355X refit for embedding widths of 64 columns and more; the reference's: "
+     "0 = intended classifier (hybrid_all_kernel.cu:261), 1 = with the size>32 guard, 2 = as shipped (:262, every window on the sparse-row path)");
+  m.def("get_rule", []() { return g_rule; });
   m.def("set_plan_params", [](int split_threshold, int segment_len, int fuse_in_launch, int slice_threshold, int n_slices, int panel_cols) {
     g_params.split_threshold = split_threshold;
     g_params.segment_len = segment_len;

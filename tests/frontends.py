@@ -66,11 +66,12 @@ class ExtensionFrontend:
         return getattr(self.m, name)
 
     def preprocess(self, col_d, rp_d, N, E, W, rule=0, num_columns=None):
+        before = self.m.get_rule()
         self.m.set_rule(int(rule))  # the reference's signature has no rule argument: module-level switch
         try:
             return self.m.preprocess(col_d, rp_d, N, E, W, -1 if num_columns is None else int(num_columns))
         finally:
-            self.m.set_rule(0)
+            self.m.set_rule(before)
 
     def build_plan(self, rp_d, col_d, bp, e2c, ht, split_threshold=0, segment_len=0, num_columns=None, fuse_in_launch=False,
                    slice_threshold=0, n_slices=0, panel_cols=0):

@@ -53,9 +53,17 @@ def test_extension_forward_and_fused(HCSPMM, oracle_mod, D):
         outs = HCSPMM.preprocess(col_d, rp_d, N, len(col), (N + 15) // 16)  # column_index FIRST (HC-SpMM_main.py:52)
     finally:
         HCSPMM.set_plan_params(0, 0)
-    want = oracle_mod.preprocess(rp, col, oracle_mod.RULE_INTENDED)
+    assert HCSPMM.get_rule() == 3  # the module's default classifier: the width-agnostic MI355X refit (set_rule(0): the reference's)
+    want = oracle_mod.preprocess(rp, col, 3)
     for w, g in zip(want, outs[:4]):
         assert g.is_cuda and g.dtype == torch.int32 and np.array_equal(w, g.cpu().numpy())
+    HCSPMM.set_rule(0)
+    try:  # the reference's coefficients: hybrid_type as the reference computes it
+        ref = HCSPMM.preprocess(col_d, rp_d, N, len(col), (N + 15) // 16)
+    finally:
+        HCSPMM.set_rule(3)
+    for w, g in zip(oracle_mod.preprocess(rp, col, oracle_mod.RULE_INTENDED), ref[:4]):
+        assert np.array_equal(w, g.cpu().numpy())
     assert int(outs[3].sum()) > 0  # some dense-tile windows
     rng = np.random.default_rng(D)
     X = rng.standard_normal((N, D)).astype(np.float32)
@@ -103,7 +111,7 @@ def test_extension_as_shipped_rule_and_side_stream(HCSPMM, oracle_mod):
     try:
         outs = HCSPMM.preprocess(col_d, rp_d, N, len(col), (N + 15) // 16)
     finally:
-        HCSPMM.set_rule(0)
+        HCSPMM.set_rule(3)
         HCSPMM.set_plan_params(0, 0)
     assert int(outs[3].sum()) == 0  # hybrid_all_kernel.cu:262 as shipped: every window sparse
     X = np.random.default_rng(0).standard_normal((N, 64)).astype(np.float32)

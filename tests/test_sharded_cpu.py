@@ -67,7 +67,7 @@ def _worker(rank, world, port, seed, D, n_panels, out_dir):
         import hcspmm
         outs = hcspmm.preprocess(torch.from_numpy(g.column_index), torch.from_numpy(g.row_pointers), g.n_local,
                                  len(g.column_index), (g.n_local + 15) // 16, num_columns=g.num_columns)
-        want_pre = oracle.preprocess(g.row_pointers, g.column_index)
+        want_pre = oracle.preprocess(g.row_pointers, g.column_index, hcspmm.default_rule())
         ok = ok and all(np.array_equal(a, b.numpy()) for a, b in zip(want_pre, outs[:4]))
         np.save(os.path.join(out_dir, "ok_%d.npy" % rank), np.array([ok, g.r0, g.r1]))
     finally:

@@ -63,7 +63,7 @@ def main():
     for case in range(args.cases):
         rp, col = random_graph(rng)
         N = len(rp) - 1
-        D = int(rng.choice([1, 2, 3, 4, 7, 8, 16, 20, 22, 31, 32, 33, 40, 64, 96, 100, 128, 130, 256, 260]))
+        D = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 16, 20, 22, 31, 32, 33, 40, 64, 70, 96, 100, 128, 130, 256, 260]))
         mode = str(rng.choice(["rule0", "rule2", "rule3", "rule4", "all_dense", "all_sparse", "plan_free", "tiny_splits", "slices", "slices"]))
         dtype = [torch.float32, torch.float16, torch.bfloat16][int(rng.integers(0, 3))]
         rule = {"rule2": 2, "rule3": 3, "rule4": 4}.get(mode, 0)
@@ -82,7 +82,7 @@ def main():
         in_launch = int(rng.choice([0, 1, 2, 2])) if fused else 0
         H_pick = None
         if in_launch == 2 and rng.random() < 0.8:  # mostly shapes the row-tile form serves (others fall back to two launches)
-            D, H_pick = int(rng.choice([32, 48, 64, 96, 128])), int(rng.choice([16, 32, 64]))
+            D, H_pick = int(rng.choice([32, 48, 64, 96, 128])), int(rng.choice([16, 32, 64, 22, 22, 7, 50, 31, 2]))  # (widths between the tile sizes: zero-padded)
         X = rng.standard_normal((N, D)).astype(np.float32)
         if in_launch:  # the same classification, plan flagged so that dense windows (1) / every tile (2: row-tile form; one column
             # pass forced half of the time so that wide embeddings take it too) are multiplied inside the aggregation launches
@@ -94,7 +94,7 @@ def main():
         def run(Xd):
             if not strided:
                 return g.forward(Xd)
-            offx, offz = int(rng.choice([0, 1, 4, 8, 32])), int(rng.choice([0, 1, 4, 8, 32]))
+            offx, offz = int(rng.choice([0, 1, 3, 4, 5, 8, 32])), int(rng.choice([0, 1, 3, 4, 5, 8, 32]))
             wide_x = torch.zeros(N, D + offx + int(rng.integers(0, 9)), dtype=Xd.dtype, device=dev)
             wide_z = torch.full((N, D + offz + int(rng.integers(0, 9))), 7.0, dtype=Xd.dtype, device=dev)
             wide_x[:, offx:offx + D] = Xd
@@ -103,7 +103,7 @@ def main():
             return wide_z[:, offz:offz + D].contiguous()
         try:
             if fused:
-                H = H_pick if H_pick else int(rng.choice([16, 32, 32, 32, 7, 64, 48]))
+                H = H_pick if H_pick else int(rng.choice([16, 32, 32, 32, 7, 64, 48, 22, 50]))
                 Wm = rng.standard_normal((D, H)).astype(np.float32)
                 Xd, Wd = torch.from_numpy(X).to(dev), torch.from_numpy(Wm).to(dev)
                 out, out2 = fe.forward_fixed32_fused(Xd, *g.args(), Wd)

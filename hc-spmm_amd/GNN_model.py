@@ -65,6 +65,18 @@ def _weight_grad(kept, d):
     return out
 
 
+def _mm(X, W):
+    """X @ W (reference: torch.mm(X, weights) / torch.mm(d, weights.transpose(0, 1)), GNN_model.py:67,76,87,110,134,150,178,194,
+    201,215,227).  N is in the millions and the widths a few dozen, so the product is one pass over X: the library's own update
+    kernel (HCSPMM.update: W staged in LDS, 16-byte loads, fp32 MFMA) streams it at twice the rate of the library GEMM torch.mm
+    picks for such shapes on MI355X (profiles/r04/gnn_epoch_kernels.log)."""
+    if X.size(0) >= 4096 and hasattr(HCSPMM, "update"):
+        out = HCSPMM.update(X.contiguous(), W)
+        if out is not None:
+            return out
+    return torch.mm(X, W)
+
+
 def _make_layer_function(name, aggregate_first, fwd_agg, bwd_agg, fwd_fused=None, bwd_fused=None, takes_output=False):
     """Build one autograd Function.  fwd_agg / bwd_agg name the HCSPMM A*X entry points; *_fused,
     when given, name the fused aggregate+update entry point used instead of (A*X then mm)."""
@@ -76,10 +88,10 @@ def _make_layer_function(name, aggregate_first, fwd_agg, bwd_agg, fwd_fused=None
                 out, agg = getattr(HCSPMM, fwd_fused)(X, *graph, weights)[:2]
             else:
                 agg = getattr(HCSPMM, fwd_agg)(X, *graph)[0]
-                out = torch.mm(agg, weights)
+                out = _mm(agg, weights)
             ctx.save_for_backward(agg, weights, *graph)
         else:
-            out = getattr(HCSPMM, fwd_agg)(torch.mm(X, weights), *graph)[0]
+            out = getattr(HCSPMM, fwd_agg)(_mm(X, weights), *graph)[0]
             ctx.save_for_backward(X, weights, *graph, *extra)
         return out
 
@@ -87,16 +99,18 @@ def _make_layer_function(name, aggregate_first, fwd_agg, bwd_agg, fwd_fused=None
         saved = ctx.saved_tensors
         kept, weights, graph, extra = saved[0], saved[1], saved[2:2 + N_GRAPH], saved[2 + N_GRAPH:]
         d_out = d_out.contiguous()
+        # (the input features of a first layer need no gradient: the reference computes one anyway -- at 4.86 M x 96 that product
+        # alone was 6 % of a GCN epoch)
+        need_dx = ctx.needs_input_grad[0]
         if aggregate_first:  # kept = A X
-            d_agg = torch.mm(d_out, weights.transpose(0, 1))
             d_w = _weight_grad(kept, d_out)
-            d_x = getattr(HCSPMM, bwd_agg)(d_agg, *graph)[0]
+            d_x = getattr(HCSPMM, bwd_agg)(_mm(d_out, weights.transpose(0, 1)), *graph)[0] if need_dx else None
         else:  # kept = X
             if bwd_fused is not None:
                 d_x, d_agg = getattr(HCSPMM, bwd_fused)(d_out, *graph, weights.transpose(0, 1), *extra)[:2]
             else:
                 d_agg = getattr(HCSPMM, bwd_agg)(d_out, *graph)[0]
-                d_x = torch.mm(d_agg, weights.transpose(0, 1))
+                d_x = _mm(d_agg, weights.transpose(0, 1)) if need_dx else None
             d_w = _weight_grad(kept, d_agg)
         return (d_x, d_w) + (None,) * (N_GRAPH + (1 if takes_output else 0))
 

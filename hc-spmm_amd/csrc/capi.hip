@@ -418,6 +418,15 @@ extern "C" int hcspmm_forward_fused(const float* X, float* out, float* out2, con
   return e == hipSuccess ? HCSPMM_OK : fail_hip(e);
 }
 
+extern "C" int hcspmm_dense_update(const float* in, const float* weights, int64_t ldr, int64_t ldc, float* out, int64_t N, int D,
+                                   int H, void* stream_v) {
+  if (N < 0 || D <= 0 || H <= 0 || (N > 0 && (!in || !weights || !out))) return HCSPMM_EINVAL;
+  if (N > INT32_MAX) return HCSPMM_ERANGE;
+  const hipError_t e = hcspmm::launch_dense_update(in, weights, (long long)ldr, (long long)ldc, out, (int)N, D, H, nullptr, 0,
+                                                   reinterpret_cast<hipStream_t>(stream_v));
+  return e == hipSuccess ? HCSPMM_OK : fail_hip(e);
+}
+
 extern "C" size_t hcspmm_weight_grad_workspace(int64_t N, int D, int H) {
   if (N <= 0 || !hcspmm::weight_grad_supported(D, H)) return 0;
   return (size_t)hcspmm::weight_grad_groups(N) * (size_t)D * (size_t)H * sizeof(float);

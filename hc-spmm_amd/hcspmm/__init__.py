@@ -24,7 +24,7 @@ __all__ = [
     "forward_fixed64_fused", "forward_final_fused", "forward_final_fused_64", "forward_GIN_final_fused", "backward",
     "backward_fixed32", "backward_fixed32_fused", "backward_final_fused", "backward_fixed64",
     "backward_fixed64_fused", "backward_final_fused_64", "backward_GIN_final_fused", "loi_reorder",
-    "apply_permutation", "weight_grad", "plan_header", "forward_rect", "forward_into", "wide_threshold", "workspace_bytes", "fused_in_launch", "build_plan", "set_default_rule", "default_rule", "RULE_INTENDED", "RULE_INTENDED_GUARD",
+    "apply_permutation", "weight_grad", "update", "plan_header", "forward_rect", "forward_into", "wide_threshold", "workspace_bytes", "fused_in_launch", "build_plan", "set_default_rule", "default_rule", "RULE_INTENDED", "RULE_INTENDED_GUARD",
     "RULE_AS_SHIPPED", "RULE_MI355X", "RULE_MI355X_WIDE", "mi355x_rule", "tune_plan",
 ]
 
@@ -453,6 +453,20 @@ def forward_into(X, Z, row_pointers, column_index, blockPartition, edgeToColumn,
                                      _ptr(hybrid_type), _ptr(row_nzr) if h is not None else ctypes.c_void_p(0),
                                      ctypes.byref(h) if h is not None else None, N, E, D, _ptr(ws), ws_bytes, stream))
     return Z
+
+
+def update(X, W):
+    """X @ W for X [N, D] (fp32, contiguous) and W [D, H] (any strides: a transposed view needs no copy) through the
+    library's streaming MFMA update kernel (hcspmm_dense_update) -- the layers' torch.mm(X, weights), which for N in the
+    millions and D, H of a few dozen is a stream over X.  Returns None when the operands are not of that kind (caller: torch.mm)."""
+    if not (X.is_cuda and W.is_cuda and X.dtype == W.dtype == torch.float32 and X.dim() == W.dim() == 2
+            and X.size(1) == W.size(0) and X.is_contiguous() and X.size(0) > 0 and W.size(1) > 0):
+        return None
+    out = torch.empty((X.size(0), W.size(1)), dtype=torch.float32, device=X.device)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(X.device).cuda_stream)
+    with _on_device(X.device):
+        check(lib().hcspmm_dense_update(_ptr(X), _ptr(W), W.stride(0), W.stride(1), _ptr(out), X.size(0), X.size(1), W.size(1), stream))
+    return out
 
 
 def weight_grad(A, B):

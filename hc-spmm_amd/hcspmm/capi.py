@@ -71,6 +71,7 @@ SYMBOLS = {
     "hcspmm_forward_fused": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _hp,
                                     _i64, _i64, _int, _vp, _sz, _vp]),
     "hcspmm_fused_in_launch": (_int, [_hp, _int, _int]),
+    "hcspmm_dense_update": (_int, [_vp, _vp, _i64, _i64, _vp, _i64, _int, _int, _vp]),
     "hcspmm_weight_grad_workspace": (_sz, [_i64, _int, _int]),
     "hcspmm_weight_grad": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _int, _int, _vp, _sz, _vp]),
     "hcspmm_loi_reorder": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, ctypes.POINTER(_i64)]),

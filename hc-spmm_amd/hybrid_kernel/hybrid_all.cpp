@@ -498,6 +498,19 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
              "apply_permutation");
     return std::vector<torch::Tensor>{rp2, col2};
   }, "relabel a CSR graph with a LOI permutation -> [row_pointers, column_index]");
+  m.def("update", [](torch::Tensor X, torch::Tensor W) -> torch::Tensor {
+    // X * W through the library's streaming update kernel (hcspmm.h hcspmm_dense_update); an undefined tensor (None) when
+    // the operands are not fp32 device matrices of that kind, so that the caller can use torch.mm
+    if (!(X.is_cuda() && W.is_cuda() && X.scalar_type() == torch::kFloat && W.scalar_type() == torch::kFloat && X.dim() == 2 &&
+          W.dim() == 2 && X.size(1) == W.size(0) && X.is_contiguous() && X.size(0) > 0 && W.size(1) > 0))
+      return torch::Tensor();
+    auto out = torch::empty({X.size(0), W.size(1)}, X.options());
+    const c10::DeviceGuard guard(X.device());
+    check_rc(hcspmm_dense_update(X.data_ptr<float>(), W.data_ptr<float>(), W.stride(0), W.stride(1), out.data_ptr<float>(), X.size(0),
+                                 (int)X.size(1), (int)W.size(1), (void*)c10::hip::getCurrentHIPStream(X.device().index()).stream()),
+             "update");
+    return out;
+  }, "X * W (the layers' update GEMM; W may be a transposed view); None if the operands are not contiguous fp32 device matrices");
   m.def("weight_grad", [](torch::Tensor A, torch::Tensor B) -> torch::Tensor {
     // dW = A^T B with K = number of nodes (hcspmm.h hcspmm_weight_grad); an undefined tensor (None) when the
     // shape is outside the kernel's range, so that the caller can use a library GEMM

@@ -333,6 +333,17 @@ int hcspmm_forward_fused(const float* X_d, float* out_d, float* out2_d, const fl
                          int embedding_dim, void* workspace_d, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The update GEMM on its own:  out[N x H] = in[N x D] * W  (fp32; in / out row-major and contiguous, W with element
+ * strides ldr / ldc, so a transposed view needs no copy).  Replaces torch.mm(X, weights) / torch.mm(d, weights.t()) in the
+ * layers (GNN_model.py:67,87,110,134,194 and the backward passes): N is in the millions and D, H a few dozen, so the product
+ * is a stream over `in`; the kernel of the fused operators' update launch (W staged in LDS once per workgroup, 16-byte loads,
+ * fp32 MFMA) runs it at twice the rate of the library GEMM picked for such shapes on MI355X.  Any D, H >= 1 (shapes outside
+ * the streaming kernel's take a plain MFMA kernel).  Deterministic.
+ * ---------------------------------------------------------------------------------------- */
+int hcspmm_dense_update(const float* in_d, const float* weights_d, int64_t ldr, int64_t ldc, float* out_d, int64_t N, int D,
+                        int H, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Weight gradient of the update GEMM, for the autograd glue around the operators:
  *   dW[D x H] = A^T * B,  A = N x D (rows lda elements apart), B = N x H (rows ldb apart), fp32, dW row-major.
  * Replaces torch.mm(X.t(), d_out) of the reference's backward passes (GNN_model.py:79,101,124,160,181,205,230):

@@ -65,15 +65,17 @@ def _dense_adj(rp, col, dev):
 @pytest.mark.gpu
 @pytest.mark.parametrize("family", ["gcn", "gin"])
 @pytest.mark.parametrize("fixed", [1, 0, 2])
-def test_layer_forward_backward_vs_dense_autograd(family, fixed):
+@pytest.mark.parametrize("nodes", [400, 5000])
+def test_layer_forward_backward_vs_dense_autograd(family, fixed, nodes):
     """Every layer class of GNN_model.py against plain dense autograd on a small SYMMETRIC graph
-    (the backward pass aggregates with A, not A^T, like the reference)."""
+    (the backward pass aggregates with A, not A^T, like the reference).  From 4 096 nodes on the layers' X*W products go
+    through the library's streaming update kernel (HCSPMM.update) instead of torch.mm."""
     _pkg_imports()
     import HCSPMM
     from GNN_model import GCNConv, GINConv
     from hcspmm import graphs
     dev = torch.device("cuda:0")
-    rp, col = graphs.powerlaw_graph(400, 3000, seed=12)  # symmetric by construction
+    rp, col = graphs.powerlaw_graph(nodes, 7 * nodes + 200, seed=12)  # symmetric by construction
     N = len(rp) - 1
     rp_d, col_d = torch.from_numpy(rp).to(dev), torch.from_numpy(col).to(dev)
     graph = (rp_d, col_d, *HCSPMM.preprocess(col_d, rp_d, N, len(col), (N + 15) // 16))
@@ -97,6 +99,34 @@ def test_layer_forward_backward_vs_dense_autograd(family, fixed):
         return (a - b).abs().max().item() <= 2e-4 * b.abs().max().item() + 1e-6
     assert close(Y.detach(), Yr.detach())
     assert close(gX, Xr.grad) and close(gW, Wr.grad)
+    # input features that need no gradient (the first layer of a model): none is computed, the weight gradient is the same
+    conv.weights.grad = None
+    Y2 = conv(X.detach(), *graph, out_buf)
+    (Y2 * R).sum().backward()
+    assert torch.equal(Y2, Y) and close(conv.weights.grad, Wr.grad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,D,H", [(5000, 32, 32), (70001, 96, 32), (4097, 32, 22), (9000, 22, 32), (6000, 32, 96), (5000, 7, 5), (4100, 128, 64)])
+def test_update_op_matches_torch_mm(N, D, H):
+    """HCSPMM.update / hcspmm.update (hcspmm_dense_update): X * W for contiguous fp32 X and W of any strides, against torch.mm in
+    fp64; deterministic; both front-ends the same bits; None (caller: torch.mm) for operands it does not take."""
+    _pkg_imports()
+    import HCSPMM
+    import hcspmm
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(N + D)
+    X = torch.randn(N, D, device=dev, generator=g)
+    W = torch.randn(D, H, device=dev, generator=g)
+    Wt = torch.randn(H, D, device=dev, generator=g).transpose(0, 1)  # a transposed view, as the backward passes hand it over
+    for w in (W, Wt):
+        out = HCSPMM.update(X, w)
+        want = X.double() @ w.double()
+        scale = X.abs().double() @ w.abs().double()
+        assert out.shape == (N, H) and bool(((out.double() - want).abs() <= 1e-5 * scale + 1e-30).all())
+        assert torch.equal(out, HCSPMM.update(X, w)) and torch.equal(out, hcspmm.update(X, w))
+    assert HCSPMM.update(X[:, ::2], W[::2]) is None and hcspmm.update(X.double(), W.double()) is None
+    assert HCSPMM.update(X.cpu(), W.cpu()) is None
 
 
 @pytest.mark.gpu

@@ -28,20 +28,26 @@ inline int elem_bytes(int dtype) { return dtype == HCSPMM_DTYPE_F32 ? 4 : 2; }
 // Per-lane access width (in elements).  fp32: 16 bytes per lane for every embedding width of at least 4 columns, whatever
 // the row strides and base addresses are -- the kernels address fp32 vectors with element alignment and move a lane whose
 // columns would run past the row back onto the row's last four (spmm_impl.h MemF32 / lane_col) -- 8 bytes for D = 2, 3
-// and single elements for D = 1.  16-bit features keep the divisibility / alignment rule (8, 4 or 1 elements per lane).
+// and single elements for D = 1.  16-bit features: below.
 int pick_vec(int dtype, int D, int64_t ldx, int64_t ldz, const void* X, const void* Z, const void* ws) {
+  // (8-byte lanes for fp32 widths up to 16 -- more lanes per row, eight loads in flight per lane -- were measured too: D = 16 is 10 %
+  // SLOWER that way, D = 12 3 % faster, D = 4 ... 8 the same: not adopted)
   if (dtype == HCSPMM_DTYPE_F32) return D >= 4 ? 4 : D >= 2 ? 2 : 1;
-  const int64_t all = (int64_t)D | ldx | ldz;
-  const size_t eb = (size_t)elem_bytes(dtype);
-  for (int v = 8; v > 2; v >>= 1)
-    if (all % v == 0 && aligned(X, v * eb) && aligned(Z, v * eb) && (!ws || aligned(ws, 4 * (size_t)v))) return v;
+  // 16-bit features: 8 (or, below 8 columns, 4) elements per lane whenever every row starts on a dword -- an even width, even row
+  // strides, 4-byte aligned bases; the fp32 workspace is always that -- the last lane moved back onto the row's last elements;
+  // single elements otherwise (odd widths or strides)
+  const bool dword_rows = ((D | ldx | ldz) & 1) == 0 && aligned(X, 4) && aligned(Z, 4) && (!ws || aligned(ws, 4));
+  // below 32 columns 8-byte lanes win: 5-8 lanes per row keep eight loads in flight per lane (L = 8), where three 16-byte lanes
+  // (L = 4) keep four -- D = 20 / 22 / 24 are 7-10 % faster that way, D = 32 is not (profiles/r04/ab_ragged_lanes_bf16.log)
+  if (dword_rows && D >= 32) return 8;
+  if (dword_rows && D >= 4) return 4;
   return 1;
 }
 
 // the access width wide_choice assumes (from the embedding width alone, so that callers can ask ahead of a launch)
 inline int nominal_vec(int dtype, int D) {
   if (dtype == HCSPMM_DTYPE_F32) return D >= 4 ? 4 : D >= 2 ? 2 : 1;
-  return (D % 8 == 0) ? 8 : (D % 4 == 0) ? 4 : 1;
+  return (D % 2 == 0 && D >= 32) ? 8 : (D % 2 == 0 && D >= 4) ? 4 : 1;
 }
 }  // namespace
 

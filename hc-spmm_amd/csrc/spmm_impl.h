@@ -104,6 +104,12 @@ __device__ __forceinline__ void rset(unsigned& v, int, unsigned w) { v = w; }
 template <int VEC> struct MemF32 { typedef float type __attribute__((ext_vector_type(VEC), aligned(4))); };
 template <> struct MemF32<1> { typedef float type; };
 
+// 16-bit rows as they are addressed in memory: DWORD-aligned vectors of packed pairs.  An even width with even row strides keeps
+// every row on the dword grid, so the same trick serves fp16 / bf16 widths that are not multiples of 8 (the last lane moved back
+// onto the row's last 8 elements): D = 22 takes three 16-byte lanes instead of 22 two-byte ones.
+template <int WORDS> struct MemU32 { typedef unsigned int type __attribute__((ext_vector_type(WORDS), aligned(4))); };
+template <> struct MemU32<1> { typedef unsigned int type; };
+
 // first of the VEC feature columns a lane covers, given the aligned position c < cend of its slot in [.., cend)
 template <int VEC> __device__ __forceinline__ int lane_col(int c, int cend) { return VEC == 1 ? c : min(c, cend - VEC); }
 
@@ -118,6 +124,7 @@ template <typename E, int VEC> struct Lane {
   }
   static __device__ __forceinline__ raw_t load(const T* p) {
     if constexpr (sizeof(T) == 4) return *reinterpret_cast<const typename MemF32<VEC>::type*>(p);
+    else if constexpr (VEC >= 2) return *reinterpret_cast<const typename MemU32<VEC / 2>::type*>(p);
     else return *reinterpret_cast<const raw_t*>(p);
   }
   static __device__ __forceinline__ acc_t load_partial(const float* p) { return *reinterpret_cast<const typename MemF32<VEC>::type*>(p); }
@@ -151,6 +158,7 @@ template <typename E, int VEC> struct Lane {
   // Z rows are written once and not re-read by this launch: non-temporal stores (0-5 %, profiles/r01/ab_nt_store.log)
   static __device__ __forceinline__ void store(T* p, const acc_t& acc) {
     if constexpr (sizeof(T) == 4) __builtin_nontemporal_store(pack(acc), reinterpret_cast<typename MemF32<VEC>::type*>(p));
+    else if constexpr (VEC >= 2) __builtin_nontemporal_store(pack(acc), reinterpret_cast<typename MemU32<VEC / 2>::type*>(p));
     else __builtin_nontemporal_store(pack(acc), reinterpret_cast<raw_t*>(p));
   }
   static __device__ __forceinline__ void store_partial(float* p, const acc_t& acc) {
@@ -1030,8 +1038,10 @@ static hipError_t launch_plan_LV(const PlanArgs& a, hipStream_t stream) {
   constexpr int VM = DenseV<VEC>::mid;
   // (16-bit features have no 4-byte-per-lane build: 32 <= D < 64 takes the 8-byte one with half the lanes idle)
   constexpr int kMidCols = (sizeof(typename E::T) == 2 && VM > 1) ? 8 * VM : 16 * VM;
-  // (fp32 widths that are not multiples of 16 count as the next one: D = 22 is ONE 32-column panel of 8-byte lanes, 11 busy)
-  const int d_panel = sizeof(typename E::T) == 4 ? (a.D + 15) / 16 * 16 : a.D;
+  // (widths that are not multiples of 16 count as the next one: fp32 D = 22 is ONE 32-column panel of 8-byte lanes, 11 busy; a
+  // 16-bit build wider than one element per lane is only launched on even widths -- capi.hip pick_vec -- so its 8-byte lanes,
+  // the last one moved back, stay on the dword grid)
+  const int d_panel = (sizeof(typename E::T) == 4 || VEC > 1) ? (a.D + 15) / 16 * 16 : a.D;
   b.dense_vec = (d_panel >= 16 * VEC) ? VEC : (d_panel >= kMidCols ? VM : 1);
   b.n_panels = (a.D + 16 * b.dense_vec - 1) / (16 * b.dense_vec);
   constexpr bool kCanFuse = sizeof(typename E::T) == 4 && VEC == 4;

@@ -369,7 +369,7 @@ def _check_h16(oracle_mod, g, X16, Z16):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
-@pytest.mark.parametrize("D", [256, 128, 64, 40, 32, 20, 7])
+@pytest.mark.parametrize("D", [256, 128, 64, 40, 32, 20, 7, 22, 6, 10, 70, 130, 4])
 @pytest.mark.parametrize("name,gen", _H16_GRAPHS, ids=[g[0] for g in _H16_GRAPHS])
 def test_half_precision_features_planned(oracle_mod, dev, fe, name, gen, D, dtype):
     rp, col = gen()
@@ -384,7 +384,7 @@ def test_half_precision_features_planned(oracle_mod, dev, fe, name, gen, D, dtyp
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
-@pytest.mark.parametrize("D", [128, 24, 5])
+@pytest.mark.parametrize("D", [128, 24, 5, 22, 70, 134])
 @pytest.mark.parametrize("mode", ["plan_free", "all_dense", "all_sparse"])
 def test_half_precision_features_other_paths(oracle_mod, dev, fe, D, dtype, mode):
     rp, col = graphs.powerlaw_graph(1500, 20000, seed=41, max_degree_frac=0.2)
@@ -400,12 +400,18 @@ def test_half_precision_strided_views_and_errors(oracle_mod, dev, fe):
     out = torch.zeros(g.N, 192, dtype=torch.bfloat16, device=dev)
     fe.forward_into(wide[:, 64:128], out[:, 128:192], *g.args())
     assert torch.equal(out[:, 128:192], g.forward(wide[:, 64:128].contiguous())) and not out[:, :128].any()
-    # views whose first element is only 8-byte / 2-byte aligned: the 4- and 1-element-per-lane builds
-    for off in (4, 1):
+    # views whose first element is only 8- / 4- / 2-byte aligned: 16-byte lanes on the dword grid, and the 1-element-per-lane build
+    for off in (4, 2, 6, 1):
         out.zero_()
         fe.forward_into(wide[:, off:off + 64], out[:, off:off + 64], *g.args())
         assert torch.equal(out[:, off:off + 64], g.forward(wide[:, off:off + 64].contiguous()))
         assert not out[:, :off].any() and not out[:, off + 64:].any()
+    # a width that is not a multiple of 8, in a view off the 16-byte grid: three overlapping 16-byte lanes per row
+    for off, D in ((2, 22), (6, 70), (0, 10)):
+        out.zero_()
+        fe.forward_into(wide[:, off:off + D], out[:, off:off + D], *g.args())
+        assert torch.equal(out[:, off:off + D], g.forward(wide[:, off:off + D].contiguous()))
+        assert not out[:, :off].any() and not out[:, off + D:].any()
     with pytest.raises(RuntimeError, match="float32 / float16 / bfloat16"):
         fe.forward_into(wide[:, :64], torch.zeros(g.N, 64, device=dev), *g.args())  # mixed dtypes
     with pytest.raises(RuntimeError, match="float32"):

@@ -374,7 +374,7 @@ static int fused_form(const hcspmm_plan_header* ph, const void* X, const void* o
   if (!(ph->flags & HCSPMM_PLAN_FUSE_IN_LAUNCH) && forced != 1) return 0;  // form 1 only where it was asked for by name
   bool dense_ok = ph->n_dense > 0 && D % 16 == 0 && D >= 32 && H % 16 == 0 && H <= 32 && H > 0;
   if (dense_ok) {
-    const int dv = D >= 64 ? 4 : 2;
+    const int dv = D <= 32 ? 2 : 4;  // (launch_plan_LV: the narrowest lane width that covers the row in one panel)
     const int rows = (D + 16 * dv - 1) / (16 * dv) * 16 * dv;
     dense_ok = (size_t)rows * (size_t)(H + 4) * sizeof(float) <= 64 * 1024;
   }

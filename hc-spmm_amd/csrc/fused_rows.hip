@@ -100,9 +100,11 @@ __device__ __forceinline__ void ordinary_tile(const PlanArgs& a, const int4* __r
   const float* X = reinterpret_cast<const float*>(a.X);
   float* Z = reinterpret_cast<float*>(a.Z);
   const int g = lane / L, s = lane & (L - 1);
-  const int cl = s * 4;      // column inside the chunk = column of the tile
+  // column inside the chunk = column of the tile; a lane whose four columns would run past a width that is not a multiple of
+  // 4 is moved back onto the last four (it then repeats its neighbour's values: spmm_impl.h lane_col)
+  const bool cok = s * 4 < width;
+  const int cl = cok ? lane_col<4>(s * 4, width) : 0;
   const int c = col0 + cl;   // feature column
-  const bool cok = cl < width;
   const int csafe = cok ? c : 0;
 #pragma unroll 1
   for (int t = 0; t < 16 / R; ++t) {
@@ -114,7 +116,7 @@ __device__ __forceinline__ void ordinary_tile(const PlanArgs& a, const int4* __r
       if (d.w < 0) Ln::store(Z + (size_t)d.x * a.ldz + c, acc);
       else Ln::store_partial(a.partial + (size_t)d.w * (size_t)a.D + c, acc);
     }
-    if (cok) *reinterpret_cast<f32x4*>(tile + (t * R + g) * TS + cl) = acc;
+    if (cok) *reinterpret_cast<typename MemF32<4>::type*>(tile + (t * R + g) * TS + cl) = acc;
     if (s == 0) trow[t * R + g] = (d.x >= 0 && d.w < 0) ? d.x : -1;  // a whole row: a row of out; segments wait for the fix-up pass
   }
 }
@@ -129,9 +131,9 @@ __device__ __forceinline__ void tiny_tile(const PlanArgs& a, const int4* __restr
   const float* X = reinterpret_cast<const float*>(a.X);
   float* Z = reinterpret_cast<float*>(a.Z);
   const int g = lane / L, s = lane & (L - 1);
-  const int cl = s * 4;
+  const bool cok = s * 4 < width;
+  const int cl = cok ? lane_col<4>(s * 4, width) : 0;
   const int c = col0 + cl;
-  const bool cok = cl < width;
   const int csafe = cok ? c : 0;
 #pragma unroll 1
   for (int st = 0; st < 16 / (R * T); ++st) {
@@ -170,7 +172,7 @@ __device__ __forceinline__ void tiny_tile(const PlanArgs& a, const int4* __restr
         else Ln::store_partial(a.partial + (size_t)(-(d[t].x + 1)) * (size_t)a.D + c, acc);
       }
       const int tr = (st * T + t) * R + g;
-      if (cok) *reinterpret_cast<f32x4*>(tile + tr * TS + cl) = acc;
+      if (cok) *reinterpret_cast<typename MemF32<4>::type*>(tile + tr * TS + cl) = acc;
       if (s == 0) trow[tr] = (d[t].z >= 0 && d[t].x >= 0) ? d[t].x : -1;
     }
   }
@@ -188,9 +190,9 @@ __device__ __forceinline__ void dense_tile(const PlanArgs& a, int unit, float* _
   int window;
 #define HCSPMM_TILE_PANELS(CHAIN)                                                         \
   for (int panel = p0; panel < p1; ++panel) {                                              \
-    const int c = panel * 16 * DV + j * DV;                                               \
-    const bool cok = c < a.D;                                                             \
-    const int csafe = cok ? c : 0;                                                        \
+    const bool cok = panel * 16 * DV + j * DV < a.D;                                      \
+    const int c = cok ? lane_col<DV>(panel * 16 * DV + j * DV, a.D) : 0;                  \
+    const int csafe = c;                                                                  \
     f32x4 acc[DV];                                                                        \
     _Pragma("unroll") for (int q = 0; q < DV; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};    \
     CHAIN;                                                                                \
@@ -199,7 +201,7 @@ __device__ __forceinline__ void dense_tile(const PlanArgs& a, int unit, float* _
       _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                     \
         typename AccT<DV>::type o;                                                        \
         _Pragma("unroll") for (int q = 0; q < DV; ++q) aset(o, q, acc[q][r]);             \
-        *reinterpret_cast<typename AccT<DV>::type*>(tile + (4 * kq + r) * TS + c - p0 * 16 * DV) = o; \
+        *reinterpret_cast<typename MemF32<DV>::type*>(tile + (4 * kq + r) * TS + c - p0 * 16 * DV) = o; \
       }                                                                                   \
     }                                                                                     \
   }
@@ -311,11 +313,19 @@ __global__ __launch_bounds__(64 * WV, (KIND == 1 && WV == 4) ? HCSPMM_ROWS_MIN_W
   float* s_w = s_mem;  // [D][HS]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float* tile = s_mem + a.D * HS + wave * (16 * TS + 16);  // [16][TS] + 16 row ids
+  // an input width that is not a multiple of 16 (the reference's 22 classes as the INPUT of the last layer's backward): the update
+  // runs over Dp = the next multiple -- the staged weights get zero rows, the tile's columns [D, Dp) are zeroed once here and never
+  // written again (the reference pads the same way, hybrid_all_kernel.cu:2748)
+  const int Dp = (a.D + 15) & ~15;
+  float* tile = s_mem + Dp * HS + wave * (16 * TS + 16);  // [16][TS] + 16 row ids
   int* trow = reinterpret_cast<int*>(tile + 16 * TS);
-  for (int i = threadIdx.x; i < a.D * H; i += 64 * WV) {
+  for (int i = threadIdx.x; i < Dp * H; i += 64 * WV) {
     const int k = i / H, h = i - k * H;
-    s_w[k * HS + h] = h < a.H ? a.W[(long long)k * a.w_ldr + (long long)h * a.w_ldc] : 0.0f;  // (a.H < H: zero columns)
+    s_w[k * HS + h] = (h < a.H && k < a.D) ? a.W[(long long)k * a.w_ldr + (long long)h * a.w_ldc] : 0.0f;  // (zero columns / rows)
+  }
+  if (Dp != a.D) {
+    const int pad = Dp - a.D;
+    for (int i = lane; i < 16 * pad; i += 64) tile[(i / pad) * TS + a.D + (i - (i / pad) * pad)] = 0.0f;
   }
   __syncthreads();
   const int4* tasks = reinterpret_cast<const int4*>(a.plan + a.off_tasks);
@@ -339,7 +349,7 @@ __global__ __launch_bounds__(64 * WV, (KIND == 1 && WV == 4) ? HCSPMM_ROWS_MIN_W
       f32x4 oacc[HT];
 #pragma unroll
       for (int t = 0; t < HT; ++t) oacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      tile_mac<HT>(tile, s_w, TS, a.D, lane, oacc);
+      tile_mac<HT>(tile, s_w, TS, Dp, lane, oacc);
       tile_store<HT>(trow, oacc, a.out, lane, a.H);
       wave_lds_fence();  // the next tile's writes stay behind these reads
     } else {
@@ -371,18 +381,18 @@ __global__ __launch_bounds__(64 * WV, (KIND == 1 && WV == 4) ? HCSPMM_ROWS_MIN_W
 // column chunk of the sparse tiles and waves per workgroup for an embedding width
 static inline int tiles_chunk(int D) { return (D > 64 && D % 64 == 0) ? 64 : D; }  // (D = 96 in chunks of 48: 12 of 16 lanes busy, two walks of every task: -25 % on the TT-sized graph)
 static inline int tiles_waves(int D) { return tiles_chunk(D) < D ? 8 : kWaves; }
-static inline int tiles_stride(int D) { return (tiles_chunk(D) < D ? 64 : D) + 4; }  // (dense panels of a chunked launch are 64 wide)
+static inline int tiles_stride(int D) { return (tiles_chunk(D) < D ? 64 : (D + 15) / 16 * 16) + 4; }  // (dense panels of a chunked launch are 64 wide)
 
 static inline int tiles_ht(int H) { return (H + 15) / 16; }  // output tiles of 16 columns; widths in between are zero-padded
 size_t fused_tiles_lds_bytes(int D, int H) {
-  return ((size_t)D * rows_w_stride(16 * tiles_ht(H)) + (size_t)tiles_waves(D) * (16 * tiles_stride(D) + 16)) * sizeof(float);
+  return ((size_t)((D + 15) / 16 * 16) * rows_w_stride(16 * tiles_ht(H)) + (size_t)tiles_waves(D) * (16 * tiles_stride(D) + 16)) * sizeof(float);
 }
 
-// shapes the row-tile form serves: fp32 rows of 16-byte pieces, one lane group of at most 32 lanes per row, one, two or four
+// shapes the row-tile form serves: fp32 rows of 17 to 128 columns (any width: the tile is zero-padded to the next multiple of 16), one lane group of at most 32 lanes per row, one, two or four
 // output tiles (H <= 32 or 49 ... 64: the reference's default 22 classes pad to 32, as its own fused kernels pad to their
 // tile, hybrid_all_kernel.cu:2748)
 bool fused_tiles_supported(int D, int H) {
-  return D % 16 == 0 && D >= 32 && D <= 128 && H >= 1 && H <= 64 && tiles_ht(H) != 3 && fused_tiles_lds_bytes(D, H) <= 64 * 1024;
+  return D >= 17 && D <= 128 && H >= 1 && H <= 64 && tiles_ht(H) != 3 && fused_tiles_lds_bytes(D, H) <= 64 * 1024;
 }
 
 // workgroups the chip holds at once (persistent launch: more than that would queue behind whole strided loops).  Asked once per
@@ -464,7 +474,7 @@ hipError_t launch_fused_tiles(const PlanArgs& a, hipStream_t stream) {
   if (tiles_chunk(a.D) < a.D) return launch_tiles_LD<16, 4, 8>(ta, stream);  // D = 128: two chunks of 64
   switch (pick_L(a.D, 4)) {
     case 8: return launch_tiles_LD<8, 2, 4>(ta, stream);                                                       // D = 32
-    case 16: return a.D >= 64 ? launch_tiles_LD<16, 4, 4>(ta, stream) : launch_tiles_LD<16, 2, 4>(ta, stream);  // D = 48, 64
+    case 16: return launch_tiles_LD<16, 4, 4>(ta, stream);  // D = 33 ... 64: one 64-column dense panel (two 32-column ones gather every row twice)
     case 32: return launch_tiles_LD<32, 4, 4>(ta, stream);                                                     // D = 80, 96, 112
     default: return hipErrorInvalidValue;
   }

@@ -1034,15 +1034,13 @@ static hipError_t launch_plan_LV(const PlanArgs& a, hipStream_t stream) {
   const int n_col_panels = (a.D + a.panel_cols - 1) / a.panel_cols;
   b.sparse_wgs = b.sparse_wgs_pp * n_col_panels;
   if (b.sparse_wgs_pp == 0) b.sparse_wgs_pp = 1;  // divisor in the kernel
-  // dense-tile panel width: 16*dense_vec columns -- never wider than the embedding (idle MFMA lanes)
+  // dense-tile panel width: 16*dense_vec columns -- the narrowest of the three lane widths that covers the embedding in ONE panel
+  // (a second panel walks the window's column list and gathers its rows again: D = 48 as 32 + 16 columns took 382 us on the
+  // YeastH-sized graph where D = 50 in one 64-column panel takes 279, profiles/r04/ab_dense_panels.log), else the widest.  A 16-bit
+  // build wider than one element per lane is only launched on even widths (capi.hip pick_vec), so its narrower lanes, the last one
+  // moved back, stay on the dword grid.
   constexpr int VM = DenseV<VEC>::mid;
-  // (16-bit features have no 4-byte-per-lane build: 32 <= D < 64 takes the 8-byte one with half the lanes idle)
-  constexpr int kMidCols = (sizeof(typename E::T) == 2 && VM > 1) ? 8 * VM : 16 * VM;
-  // (widths that are not multiples of 16 count as the next one: fp32 D = 22 is ONE 32-column panel of 8-byte lanes, 11 busy; a
-  // 16-bit build wider than one element per lane is only launched on even widths -- capi.hip pick_vec -- so its 8-byte lanes,
-  // the last one moved back, stay on the dword grid)
-  const int d_panel = (sizeof(typename E::T) == 4 || VEC > 1) ? (a.D + 15) / 16 * 16 : a.D;
-  b.dense_vec = (d_panel >= 16 * VEC) ? VEC : (d_panel >= kMidCols ? VM : 1);
+  b.dense_vec = a.D <= 16 ? 1 : (a.D <= 16 * VM ? VM : VEC);
   b.n_panels = (a.D + 16 * b.dense_vec - 1) / (16 * b.dense_vec);
   constexpr bool kCanFuse = sizeof(typename E::T) == 4 && VEC == 4;
   constexpr int kMinWaves = sizeof(typename E::T) == 4 ? HCSPMM_MIN_WAVES_PER_SIMD : HCSPMM_MIN_WAVES_H16;

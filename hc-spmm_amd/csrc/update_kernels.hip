@@ -201,9 +201,10 @@ __global__ __launch_bounds__(kUpdWaves * 64) void dense_update_rows_kernel(const
   extern __shared__ __attribute__((aligned(16))) float s_w[];
   constexpr int H = 16 * T;
   constexpr int HS = H + 4;
-  for (int i = threadIdx.x; i < D * H; i += kUpdWaves * 64) {
+  const int Dp = (D + 15) & ~15;  // (D off the 16-column grid: zero rows in the staged weights, masked loads of the row's tail)
+  for (int i = threadIdx.x; i < Dp * H; i += kUpdWaves * 64) {
     const int k = i / H, h = i - k * H;
-    s_w[k * HS + h] = h < Hreal ? W[(long long)k * ldr + (long long)h * ldc] : 0.0f;  // (Hreal < 16*T: zero columns, masked stores)
+    s_w[k * HS + h] = (h < Hreal && k < D) ? W[(long long)k * ldr + (long long)h * ldc] : 0.0f;  // (zero columns / rows, masked stores)
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(kUpdWaves * 64) void dense_update_rows_kernel(const
     }
     if (__builtin_amdgcn_ballot_w64(row >= 0) == 0) continue;  // wave-uniform
     const bool rok = row >= 0;
-    const f32x4* arow = reinterpret_cast<const f32x4*>(in + (size_t)(rok ? row : 0) * (size_t)D) + kq;
+    const float* arow = in + (size_t)(rok ? row : 0) * (size_t)D + 4 * kq;
     f32x4 acc[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -237,7 +238,14 @@ __global__ __launch_bounds__(kUpdWaves * 64) void dense_update_rows_kernel(const
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (rok && k0 + 16 * u < D) a[u] = arow[(k0 >> 2) + 4 * u];
+        const int k = k0 + 16 * u + 4 * kq;  // columns k .. k + 3 of this lane's row
+        if (rok && k + 3 < D) {
+          a[u] = *reinterpret_cast<const upd_f32x4*>(arow + k0 + 16 * u);
+        } else if (rok && k < D) {  // the row's tail
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+            if (k + q < D) a[u][q] = arow[k0 + 16 * u + q];
+        }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -269,7 +277,7 @@ template <int T>
 static hipError_t launch_rows(const float* in, const float* W, long long ldr, long long ldc, float* out, int D, int H,
                               const int* plan, int off_tasks, int n_wide, int off_fixups, int n_split_rows,
                               int off_slice_tasks, int n_slice_tasks, hipStream_t stream) {
-  const size_t lds = (size_t)D * (16 * T + 4) * sizeof(float);
+  const size_t lds = (size_t)((D + 15) / 16 * 16) * (16 * T + 4) * sizeof(float);
   const long long n_tiles = ((long long)n_wide + n_split_rows + n_slice_tasks + 15) / 16;
   int grid = (int)((n_tiles + kUpdWaves - 1) / kUpdWaves);
   if (grid > 1024) grid = 1024;
@@ -498,7 +506,7 @@ hipError_t launch_dense_update_leftover(const float* in, const float* W, long lo
                                         int n_split_rows, int off_slice_tasks, int n_slice_tasks, hipStream_t stream) {
   if (N <= 0 || (long long)n_wide + n_split_rows + n_slice_tasks <= 0) return hipSuccess;
   const int T = (H + 15) / 16;  // output tiles; a width in between is zero-padded to the tile (the row-tile form's shapes)
-  if (D % 16 != 0 || D > 128 || H < 1 || H > 64 || T == 3 || ((uintptr_t)in & 15) != 0) return hipErrorInvalidValue;
+  if (D < 1 || D > 128 || H < 1 || H > 64 || T == 3) return hipErrorInvalidValue;
 #define HCSPMM_ROWS_CASE(T_) \
   return launch_rows<T_>(in, W, ldr, ldc, out, D, H, plan, off_tasks, n_wide, off_fixups, n_split_rows, off_slice_tasks, n_slice_tasks, stream);
   if (T == 4) { HCSPMM_ROWS_CASE(4) }

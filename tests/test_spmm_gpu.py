@@ -470,7 +470,7 @@ def _wide_window_graph(seed=11):
 
 @pytest.mark.parametrize("D,H", [(32, 32), (64, 64), (96, 22), (32, 7), (16, 40), (128, 32), (48, 16), (256, 32), (16, 16),
                                  (96, 16), (128, 64), (64, 32), (32, 16), (512, 32), (22, 32), (22, 22), (32, 96), (6, 50),
-                                 (32, 22), (64, 22), (64, 50), (128, 22), (32, 2), (48, 31), (32, 40)])
+                                 (32, 22), (64, 22), (64, 50), (128, 22), (32, 2), (48, 31), (32, 40), (50, 32), (70, 16), (18, 7), (100, 22)])
 @pytest.mark.parametrize("gname,gen", _FUSED_GRAPHS, ids=[g[0] for g in _FUSED_GRAPHS])
 @pytest.mark.parametrize("form", ["two_launches", "in_launch", "row_tiles"])
 def test_fused_variants(oracle_mod, dev, fe, gname, gen, D, H, form):
@@ -499,8 +499,9 @@ def test_fused_variants(oracle_mod, dev, fe, gname, gen, D, H, form):
     dense_ok = D % 16 == 0 and D >= 32 and H in (16, 32) and D * (H + 4) * 4 <= 64 * 1024
     chunked = D == 128  # two column chunks of 64 summed one after the other, eight waves per workgroup
     Hp = (H + 15) // 16 * 16  # hidden widths between the tile sizes are zero-padded to one, two or four 16-column output tiles
-    lds = (D * (Hp + 4) + (8 if chunked else 4) * (16 * ((64 if chunked else D) + 4) + 16)) * 4
-    rows_ok = D % 16 == 0 and 32 <= D <= 128 and 1 <= H <= 64 and Hp != 48 and lds <= 64 * 1024
+    Dp = (D + 15) // 16 * 16  # ... and input widths to the next multiple of 16 (zero rows in the staged weights, zero tile columns)
+    lds = (Dp * (Hp + 4) + (8 if chunked else 4) * (16 * ((64 if chunked else Dp) + 4) + 16)) * 4
+    rows_ok = 17 <= D <= 128 and 1 <= H <= 64 and Hp != 48 and lds <= 64 * 1024
     assert hcspmm.fused_in_launch(g.row_nzr, D, H) == (2 if asked == 2 and rows_ok else (1 if asked == 1 and h.n_dense > 0 and dense_ok else 0))
     if gname not in ("powerlaw", "hubs"):
         assert h.n_dense > 0

@@ -364,6 +364,9 @@ static int fused_form(const hcspmm_plan_header* ph, const void* X, const void* o
       const double out2_bytes = (double)ph->num_nodes * (double)D * 4.0;
       const bool dense_heavy = 64.0 * (double)ph->n_dense >= (double)ph->num_nodes;  // a quarter of the rows in dense-tile windows
       asked = (D <= 64 ? out2_bytes >= 80e6 : (D <= 128 && H <= 32 && dense_heavy && out2_bytes >= 256e6)) ? 2 : 0;
+      // (both widths off the 16-column grid -- 22 x 22 -- is the one padded shape that measured slower than two launches on the
+      // sparse-row graphs, -9 ... -12 %: profiles/r04/ab_dense_panels.log; it stays opt-in)
+      if (D % 16 != 0 && H % 16 != 0) asked = 0;
     }
   }
   if (asked == 0) return 0;

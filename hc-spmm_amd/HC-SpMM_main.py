@@ -47,6 +47,11 @@ def parse_args(argv=None):
     # addition: measure the launch-plan variants no size rule predicts (column slices, panel width) on THIS graph and
     # GPU and keep the fastest (hcspmm.tune_plan: a few plan builds and a few hundred launches before the first epoch)
     p.add_argument("--tune", action="store_true", help="tune the launch plan on this graph before training")
+    # addition: the LOI layout reorder as a step of the driver.  The reference ships it as a separate file-to-file program
+    # (LOI.cpp main, :807-896, writes reorder_direct.txt) and no code that applies the order; here the graph is relabelled in
+    # memory before preprocess, features and labels move with their vertices.  "fast": the relaxed parallel variant
+    # (hcspmm_loi_reorder_fast); "exact": reorder_plus_new_direct bit for bit (seconds on large graphs).
+    p.add_argument("--loi", type=str, default="none", choices=["none", "fast", "exact"], help="reorder the graph (LOI) before preprocessing")
     return p.parse_args(argv)
 
 
@@ -88,6 +93,15 @@ def main(argv=None):
                              load_from_txt=True, device=device)
     num_nodes, num_edges = dataset.num_nodes, dataset.num_edges
     num_row_windows = (num_nodes + BLK_H - 1) // BLK_H
+    if args.loi != "none":
+        start = time.perf_counter()
+        reorder = HCSPMM.loi_reorder_fast if args.loi == "fast" else HCSPMM.loi_reorder
+        perm, group_sizes = reorder(dataset.row_pointers, dataset.column_index)
+        dataset.row_pointers, dataset.column_index = HCSPMM.apply_permutation(dataset.row_pointers, dataset.column_index, perm)
+        order = perm.to(device=device, dtype=torch.long)  # new vertex i is old vertex perm[i]
+        dataset.x, dataset.y = dataset.x[order], dataset.y[order]
+        print("LOI (ms):\t{:.3f}\t{} groups, {} of them full".format((time.perf_counter() - start) * 1e3, group_sizes.numel(),
+                                                                   int((group_sizes == 16).sum())))
     column_index = dataset.column_index.to(device)
     row_pointers = dataset.row_pointers.to(device)
     output = torch.zeros(num_nodes, args.hidden, device=device)

@@ -149,6 +149,36 @@ def test_sag_profile_and_known_answer_tensor(capsys):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["fast", "exact"])
+def test_driver_reorders_the_graph_when_asked(variant, capsys, monkeypatch):
+    """--loi: the graph is relabelled in memory before preprocess and features / labels move with their vertices, so the
+    reordered run computes the same model on an isomorphic graph: with dropout off and the same weights the outputs are the
+    unreordered ones, permuted."""
+    _pkg_imports()
+    monkeypatch.chdir(PKG)
+    spec = importlib.util.spec_from_file_location("hc_spmm_main_loi", os.path.join(PKG, "HC-SpMM_main.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    common = ["--dataset", "example", "--dim", "16", "--num_layers", "3", "--hidden", "32", "--classes", "22", "--epochs", "0", "--model", "gcn"]
+    torch.manual_seed(0)
+    plain = mod.main(common)
+    torch.manual_seed(0)
+    moved = mod.main(common + ["--loi", variant])
+    out = capsys.readouterr().out
+    assert "LOI (ms):" in out
+    moved.load_state_dict(plain.state_dict())
+    plain.eval()
+    moved.eval()
+    with torch.no_grad():
+        a, b = plain(), moved()
+    # moved.dataset.x is plain.dataset.x permuted: recover the permutation from the (random, distinct) feature rows
+    key = {tuple(r.tolist()): i for i, r in enumerate(plain.dataset.x.cpu())}
+    order = torch.tensor([key[tuple(r.tolist())] for r in moved.dataset.x.cpu()], device=a.device)
+    assert sorted(order.tolist()) == list(range(a.size(0)))
+    assert torch.allclose(b, a[order], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
 def test_driver_graph_replay_trains(capsys, monkeypatch):
     """--graph: the whole training step (HCSPMM forward/backward operators, Adam) replayed from a HIP
     graph; the loss must move exactly as it does when the same steps are launched eagerly."""

@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstdint>
 #include <cstring>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -355,8 +356,17 @@ extern "C" int hcspmm_loi_reorder_fast(const int32_t* rowptr, const int32_t* col
   cpu_set_t caller_mask, near_mask;
   const char* pin_mode = std::getenv("HCSPMM_LOI_PIN");
   if (!pin_mode) pin_mode = "l3";
-  const bool pinned = T > 1 && std::string(pin_mode) != "off" && sched_getaffinity(0, sizeof(caller_mask), &caller_mask) == 0 &&
-                      locality_cpuset(pin_mode, &near_mask) && sched_setaffinity(0, sizeof(near_mask), &near_mask) == 0;
+  // (a domain with fewer CPUs than half the threads would crowd them: the L3 domain of a desktop part or of a small VM; then the
+  // NUMA node is tried, then nothing is pinned)
+  bool pinned = false;
+  if (T > 1 && std::string(pin_mode) != "off" && sched_getaffinity(0, sizeof(caller_mask), &caller_mask) == 0) {
+    bool have = locality_cpuset(pin_mode, &near_mask) && 2 * CPU_COUNT(&near_mask) >= T;
+    if (!have && std::string(pin_mode) == "l3") {
+      pin_mode = "node";
+      have = locality_cpuset(pin_mode, &near_mask) && 2 * CPU_COUNT(&near_mask) >= T;
+    }
+    pinned = have && sched_setaffinity(0, sizeof(near_mask), &near_mask) == 0;
+  }
   struct Restore {
     bool on;
     cpu_set_t* m;
@@ -445,8 +455,11 @@ extern "C" int hcspmm_loi_reorder_fast(const int32_t* rowptr, const int32_t* col
   const double t_incsr = now();
   std::vector<uint64_t> placed(((size_t)N + 63) / 64 + 1, 0);
   std::vector<int32_t> claim((size_t)N, INT32_MAX);
-  std::vector<int32_t> members, sizes, seeds((size_t)batch);  // members: 16 slots per group, creation order
-  members.reserve((size_t)N * 2 + 16 * (size_t)batch);  // (N / 8 groups: address space only until used)
+  // members: 16 slots per group, one uninitialised block per round (a zero-filled, growing vector cost page faults and copies)
+  std::vector<std::unique_ptr<int32_t[]>> round_members;
+  std::vector<int64_t> round_first;  // index of a round's first group
+  int32_t* cur_members = nullptr;
+  std::vector<int32_t> sizes, seeds((size_t)batch);
   sizes.reserve((size_t)N / 8 + (size_t)batch);
   Shared g{rowptr, col, col_in.data(), meta.data(), placed.data(), deg8.data(), list_cap};
 
@@ -478,7 +491,11 @@ extern "C" int hcspmm_loi_reorder_fast(const int32_t* rowptr, const int32_t* col
             if (rowptr[v + 1] > rowptr[v]) seeds[(size_t)n_seeds++] = (int32_t)v;
           }
         }
-        members.resize((size_t)(base + n_seeds) * 16);
+        if (n_seeds > 0) {
+          round_members.emplace_back(new int32_t[(size_t)n_seeds * 16]);
+          round_first.push_back(base);
+          cur_members = round_members.back().get();
+        }
         sizes.resize((size_t)(base + n_seeds));
         next.store(0, std::memory_order_relaxed);
       }
@@ -517,7 +534,7 @@ extern "C" int hcspmm_loi_reorder_fast(const int32_t* rowptr, const int32_t* col
           if (w.stage == Grower::kIdle) continue;
           if (w.advance(g)) continue;
           sizes[(size_t)(base + w.index)] = w.n;
-          std::memcpy(&members[(size_t)(base + w.index) * 16], w.out, sizeof(int32_t) * (size_t)w.n);
+          std::memcpy(&cur_members[(size_t)w.index * 16], w.out, sizeof(int32_t) * (size_t)w.n);
           if (n_seeds > 1) {
             const int32_t id = (int32_t)(base + w.index);
             for (int k = 0; k < w.n; ++k) {
@@ -536,7 +553,7 @@ extern "C" int hcspmm_loi_reorder_fast(const int32_t* rowptr, const int32_t* col
       // every group keeps the members it won (order kept) and places them
       const int64_t per = (n_seeds + T - 1) / T;
       for (int64_t i = t * per; i < std::min(n_seeds, (t + 1) * per); ++i) {
-        int32_t* out = &members[(size_t)(base + i) * 16];
+        int32_t* out = &cur_members[(size_t)i * 16];
         const int n = sizes[(size_t)(base + i)];
         int keep = 0;
         for (int k = 0; k < n; ++k) {
@@ -559,10 +576,15 @@ extern "C" int hcspmm_loi_reorder_fast(const int32_t* rowptr, const int32_t* col
 
   const double t_groups = now();
   int64_t q = 0, n_groups = 0;
-  for (size_t i = 0; i < sizes.size(); ++i)
-    if (sizes[i] == 16) for (int k = 0; k < 16; ++k) perm_out[q++] = members[i * 16 + k];
-  for (size_t i = 0; i < sizes.size(); ++i)
-    if (sizes[i] < 16) for (int k = 0; k < sizes[i]; ++k) perm_out[q++] = members[i * 16 + k];
+  round_first.push_back((int64_t)sizes.size());
+  for (int pass = 0; pass < 2; ++pass)  // full groups first, then the short ones (LOI.cpp:873-891)
+    for (size_t r = 0; r + 1 < round_first.size(); ++r)
+      for (int64_t i = round_first[r]; i < round_first[r + 1]; ++i) {
+        const int n = sizes[(size_t)i];
+        if ((n == 16) != (pass == 0)) continue;
+        const int32_t* m = round_members[r].get() + (size_t)(i - round_first[r]) * 16;
+        for (int k = 0; k < n; ++k) perm_out[q++] = m[k];
+      }
   for (int64_t i = 0; i < N; ++i)
     if (!is_placed(placed.data(), (int32_t)i)) perm_out[q++] = (int32_t)i;
   for (size_t i = 0; i < sizes.size(); ++i)

@@ -246,7 +246,10 @@ def mi355x_rule(D):
 def loi_plan():
     """The `loi` block's cases: {as shuffled, after the reorder} x {the reference's classifier, the MI355X refit} at the headline
     width and at the paper's (GNN_model.py:39 calls the D = 32 kernel)."""
-    return [(w, D, r) for D in (128, 32) for w in ("community", "community_loi") for r in (0, mi355x_rule(D))]
+    plan = [(w, D, r) for D in (128, 32) for w in ("community", "community_loi") for r in (0, mi355x_rule(D))]
+    # ... and the reordered graph with every window forced onto the sparse-row path (rule 2, the reference's as-shipped line): what
+    # the dense-tile / MFMA path itself contributes on top of the locality the reorder brings
+    return plan + [("community_loi", D, 2) for D in (128, 32)]
 
 
 def _read_counter_segments(d):
@@ -995,7 +998,8 @@ def loi_block(fe, dev, args, graph_of, pmc, info):
             check = oracle_sample_check(rp, col, op.X_pm[0], op.Z_pm[0])
             live = (pmc or {}).get(case_key(wl, D, "f32", rule)) if pmc and "error" not in pmc else None
             e = {"graph": "as shuffled" if wl == "community" else "after LOI reorder", "dim": D, "rule": rule,
-                 "classifier": "reference (RTX 3090 fit, hybrid_all_kernel.cu:261)" if rule == 0 else "MI355X refit (%s)" % ("narrow" if rule == 3 else "wide"),
+                 "classifier": {0: "reference (RTX 3090 fit, hybrid_all_kernel.cu:261)", 2: "none: every window on the sparse-row path (hybrid_all_kernel.cu:262 as shipped)",
+                                3: "MI355X refit (narrow)", 4: "MI355X refit (wide)"}[rule],
                  "nodes": n, "entries": case["E"], "kernel_ms": case["kernel_ms"], "ms_per_step": case["elapsed"] / steps * 1e3,
                  "value": case["E"] * D / (case["elapsed"] / steps), "unit": "edge*dim/s",
                  "dense_windows": h.n_dense, "windows": (n + 15) // 16, "dense_window_share": h.n_dense / max((n + 15) // 16, 1),
@@ -1027,6 +1031,10 @@ def loi_block(fe, dev, args, graph_of, pmc, info):
                                                  "reordered": 100.0 * (b0["kernel_ms"] - b1["kernel_ms"]) / b0["kernel_ms"]}}
             if "fabric_bytes" in a0 and "fabric_bytes" in b0:
                 summary["dim%d" % D]["fabric_bytes"] = {"shuffled_rule0": a0["fabric_bytes"], "reordered_rule0": b0["fabric_bytes"]}
+            s2 = by_key.get(("community_loi", D, 2))
+            if s2:
+                summary["dim%d" % D]["reordered_all_sparse_ms"] = s2["kernel_ms"]
+                summary["dim%d" % D]["dense_tile_path_gain_percent"] = 100.0 * (s2["kernel_ms"] - b1["kernel_ms"]) / s2["kernel_ms"]
         out["summary"] = summary
         if os.environ.get("HCSPMM_BENCH_LOI_EPOCHS", "1") == "1":
             ep = {}

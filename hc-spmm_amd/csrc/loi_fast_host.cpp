@@ -355,7 +355,10 @@ extern "C" int hcspmm_loi_reorder_fast(const int32_t* rowptr, const int32_t* col
   // keep the threads of this call together (see locality_cpuset); the caller's own mask is put back at the end
   cpu_set_t caller_mask, near_mask;
   const char* pin_mode = std::getenv("HCSPMM_LOI_PIN");
-  if (!pin_mode) pin_mode = "l3";
+  // default: the caller's L3 domain for low-degree graphs (a chain of cache misses per group: SMT siblings and a shared L3 help), its
+  // NUMA node for denser ones (hash inserts and pricing scans over thousands of candidates per group want whole cores: the Reddit-scale
+  // graph takes 0.71 s on 16 hardware threads of one L3 domain, 0.45-0.5 s on 16 cores of the node)
+  if (!pin_mode) pin_mode = E <= 8 * N ? "l3" : "node";
   // (a domain with fewer CPUs than half the threads would crowd them: the L3 domain of a desktop part or of a small VM; then the
   // NUMA node is tried, then nothing is pinned)
   bool pinned = false;

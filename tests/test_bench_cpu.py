@@ -148,3 +148,40 @@ def test_counter_segments_follow_the_preprocess_marker(tmp_path):
     assert len(segs) == 2
     assert segs[0]["FETCH_SIZE"] == {"void hcspmm::hybrid_plan_kernel<hcspmm::F32, 8, 4, 8, 5, false>": 200.0, "void hcspmm::fixup_kernel<hcspmm::F32, 4>": 20.0}
     assert segs[1]["FETCH_SIZE"] == {"void hcspmm::hybrid_plan_kernel<hcspmm::F32, 8, 4, 8, 5, false>": 7.0}
+
+
+def test_loi_block_plan_and_case_keys():
+    """The `loi` block's cases: {as shuffled, after the reorder} x {the reference's classifier, the refit for the width} at both
+    widths, plus the reordered graph with every window on the sparse-row path; every case has its own counter key."""
+    plan = bench.loi_plan()
+    assert len(plan) == 10 and len({bench.case_key(w, D, "f32", r) for w, D, r in plan}) == 10
+    for D in (128, 32):
+        for w in ("community", "community_loi"):
+            assert (w, D, 0) in plan and (w, D, bench.mi355x_rule(D)) in plan
+        assert ("community_loi", D, 2) in plan and ("community", D, 2) not in plan
+    assert bench.mi355x_rule(32) == 3 and bench.mi355x_rule(64) == 4 and bench.DEFAULT_RULE == 3
+    assert bench.case_key("reddit", 128) == "reddit_d128" and bench.case_key("community_loi", 32, "f32", 3) == "community_loi_d32_r3"
+    assert bench.case_key("reddit", 128, "bf16") == "reddit_d128_bf16"
+
+
+def test_loi_block_host_side_and_oracle_sample_check():
+    """reorder_for_loi_block on a small community graph (the relaxed reorder, the permutation applied, the exact reorder's time) and
+    the sampled-row oracle check the block runs on every case -- here against a product made by the oracle itself, and against a
+    corrupted one."""
+    import numpy as np
+    import torch
+    import oracle
+    from hcspmm import graphs
+    rp, col, grp = graphs.community_graph(30000, 63000, seed=2)
+    info = {}
+    rpr, colr = bench.reorder_for_loi_block(rp, col, info)
+    assert len(rpr) == len(rp) and len(colr) == len(col) and int(rpr[-1]) == len(col)
+    assert info["reorder_s"] > 0 and info["apply_permutation_s"] > 0 and info["full_groups"] > 0 and info["exact"]["full_groups"] > 0
+    assert sorted(np.diff(rpr).tolist()) == sorted(np.diff(rp).tolist())  # an isomorphic graph: the same degree multiset
+    X = np.random.default_rng(0).standard_normal((30000, 16)).astype(np.float32)
+    Z = oracle.spmm_f32(rpr, colr, X)
+    ok = bench.oracle_sample_check(rpr, colr, torch.from_numpy(X), torch.from_numpy(Z), n_rows=500)
+    assert ok["ok"] and ok["rows"] >= 500 and ok["worst_over_1e-5_bar"] <= 1.0
+    Zbad = Z.copy()
+    Zbad[np.argsort(np.diff(rpr))[-1]] += 1.0  # the longest row is always in the sample
+    assert not bench.oracle_sample_check(rpr, colr, torch.from_numpy(X), torch.from_numpy(Zbad), n_rows=500)["ok"]

@@ -338,7 +338,7 @@ extern "C" int hcspmm_forward(const float* X, float* Z, const int32_t* rowptr, c
 // 2 ("row-tile", fused_rows.hip): tiles of 16 consecutive tasks of the length-sorted list, and dense windows, are summed,
 // written to out2, parked in LDS and multiplied before they leave the CU; the hybrid launch keeps the sliced and wide tasks,
 // whose rows (a few thousand) a small launch multiplies behind the fix-up pass.  `out` has form 0's bits.  Needs the sparse
-// region in ONE column pass (D < 64, or a short-row graph), 32 <= D <= 128, D % 16 == 0, H = 16, 32 or 64.
+// region in ONE column pass (D < 64, or a short-row graph), 17 <= D <= 128, H <= 32 or 49 ... 64 (widths off the 16-column grid padded).
 // Which one: HCSPMM_FUSED_SINGLE_LAUNCH=0 / 1 / 2 in the environment, else the plan's flags (fuse_in_launch = -1 / 1 / 2),
 // else automatic: form 2 when out2 (N x D fp32) is 80 MB or more at D <= 64 -- it is then beyond what the update launch
 // finds in the caches next to X and out, and not re-reading it is worth +2 ... +34 % (profiles/r03/ab_fused_rows.log: TT / RD /

@@ -65,8 +65,8 @@ struct WindowArgs {
   int N, D;
 };
 
-// vec = elements per lane access (fp32: 4, 2 or 1; 16-bit: 8, 4 or 1): the caller guarantees D, ldx,
-// ldz % vec == 0, that X and Z are aligned to vec elements and the fp32 workspace to 4*vec bytes.
+// vec = elements per lane access.  fp32: 4 for every D >= 4 (element-aligned vectors: any stride, any base address), 2 / 1 for
+// D = 2, 3 / 1.  16-bit: 8 (D >= 32) or 4 when D and the strides are even and the bases 4-byte aligned (dword-aligned vectors), else 1.
 hipError_t launch_plan_f32(const PlanArgs& a, int vec, hipStream_t stream);
 hipError_t launch_window_f32(const WindowArgs& a, int vec, hipStream_t stream);
 hipError_t launch_plan_f16(const PlanArgs& a, int vec, hipStream_t stream);

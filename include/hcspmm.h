@@ -310,7 +310,7 @@ int32_t hcspmm_wide_threshold_typed(const hcspmm_plan_header* header_h, int embe
  *   rows of out2 from the registers, park the 16 x D tile in a wave-private LDS area and run the update's MFMA chain on
  *   it (weights staged in LDS once per workgroup), so out2 is never read back.  Rows summed by whole waves or in pieces
  *   (wide tasks, split and column-sliced rows) stay in the hybrid launch and are multiplied by a small launch behind the
- *   fix-up pass.  fp32, D a multiple of 16 in [32, 128], H = 16, 32 or 64, sparse region in one column pass (D < 64, or a
+ *   fix-up pass.  fp32, D in [17, 128] and H <= 32 or 49 ... 64 (widths off the 16-column grid are zero-padded inside the launch), sparse region in one column pass (D < 64, or a
  *   short-row graph, or hcspmm_plan_params.panel_cols < 0); D = 128 is summed in two column chunks of 64 (eight-wave
  *   workgroups, `out` accumulated over the chunks in the same order).  +2 ... +34 % over form 0 wherever out2 is 80 MB or
  *   more at D <= 64, +5 ... +22 % on dense-heavy graphs up to D = 128 with H <= 32 (profiles/r03/ab_fused_rows.log) --

@@ -38,7 +38,10 @@
 // All section offsets are multiples of 4 words, the compact sections' of 64.  With slices the sections are sized
 // by upper bounds that do not depend on the column ids (hcspmm_plan_words has none): the header holds the real counts.
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -241,11 +244,7 @@ extern "C" int hcspmm_plan_words(const int32_t* rowptr, int64_t N, int64_t E, co
 }
 
 // power-of-two length class: 0 -> 0, 1 -> 1, 2 -> 2, 3..4 -> 3, 5..8 -> 4, 9..16 -> 5, 17..32 -> 6, ...
-static inline int length_class(int32_t len) {
-  int c = 0;
-  while (len > 0) { ++c; len = (len == 1) ? 0 : (len + 1) / 2; }
-  return c;
-}
+static inline int length_class(int32_t len) { return len <= 1 ? (len > 0 ? 1 : 0) : 33 - __builtin_clz((uint32_t)len - 1u); }
 
 // fingerprint of (rowptr, col) + range check of col against [0, M): one parallel pass over both arrays
 static int fingerprint_and_check(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, int64_t M, uint64_t* out) {
@@ -289,11 +288,16 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
   if (N > INT32_MAX - 16 || E > INT32_MAX) return HCSPMM_ERANGE;
   if (M <= 0) M = N;
   if (M > INT32_MAX) return HCSPMM_ERANGE;
+  // HCSPMM_PLAN_DEBUG=1: the phases' wall times on stderr
+  static const bool dbg = std::getenv("HCSPMM_PLAN_DEBUG") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tp[8] = {now(), 0, 0, 0, 0, 0, 0, 0};
   uint64_t fingerprint = 0;
   {
     const int frc = fingerprint_and_check(rowptr, col, N, E, M, &fingerprint);
     if (frc != HCSPMM_OK) return frc;
   }
+  tp[1] = now();
   const Resolved rp = resolve(params);
   Layout L;
   int rc = HCSPMM_OK;
@@ -314,6 +318,7 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
   if (words < L.total) return HCSPMM_EINVAL;
   const int64_t W = (N + HCSPMM_BLK_H - 1) / HCSPMM_BLK_H;
   const int S = slicing ? rp.n_slices : 0;
+  tp[2] = now();
 
   // Threads work on contiguous window ranges; every output position follows from per-thread counts in
   // range order, so the blob is identical for any thread count.
@@ -363,6 +368,7 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
     }
   }
 
+  tp[3] = now();
   // ---- sparse tasks.  Order: by descending power-of-two length class (0, 1, 2, 3-4, 5-8, 9-16, ...), rows
   // ascending inside a class.  Classes keep the lane groups of a wave within 2x of each other and put the
   // heavy work first; row order inside a class keeps the Z stores, the column-index reads and the
@@ -494,6 +500,7 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
     for (int x = 0; x < 8; ++x) slice_xcd_tasks = std::max(slice_xcd_tasks, xcd[x]);
     for (int sl = 0; sl <= S; ++sl) plan[L.off_slice_table + sl] = (int32_t)table[(size_t)sl];
   }
+  tp[4] = now();
   struct DenseRef { int32_t w, K; };
   std::vector<DenseRef> dense((size_t)L.n_dense);
   int32_t* out = plan + L.off_tasks;
@@ -539,6 +546,7 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
          });
   });
 
+  tp[5] = now();
   // ---- dense windows: widest first (stable, so window order inside a width); pack U and the MFMA lane masks
   std::stable_sort(dense.begin(), dense.end(), [](const DenseRef& a, const DenseRef& b) { return a.K > b.K; });
   int32_t* dindex = plan + L.off_dense_index;
@@ -638,6 +646,12 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
   h.panel_cols = rp.panel_cols;
   static_assert(sizeof(hcspmm_plan_header) == HCSPMM_PLAN_HEADER_WORDS * 4, "header size");
   std::memcpy(plan, &h, sizeof(h));
+  if (dbg) {
+    tp[6] = now();
+    std::fprintf(stderr, "plan_build: T=%d: fingerprint + range check %.2f | layout %.2f | clear + slice boundaries %.2f | task pass 1 (count) %.2f | "
+                         "task pass 2 (write) %.2f | dense packs %.2f | total %.2f ms\n",
+                 T, tp[1] - tp[0], tp[2] - tp[1], tp[3] - tp[2], tp[4] - tp[3], tp[5] - tp[4], tp[6] - tp[5], tp[6] - tp[0]);
+  }
   return HCSPMM_OK;
 }
 

@@ -204,7 +204,11 @@ struct Grower {
           const int32_t c = g.col[e];
           cols.slot(c, &fresh);
           if (fresh) ++ncols;
-          if (fresh || n == 1) {  // (the seed's columns are walked like any residual, duplicates too, as the exact code does)
+          // (the seed's columns are walked like any residual, duplicates too, as the exact code does.  With a list cap, a member's
+          // columns beyond the first 4 * list_cap new ones still count for the profit but are not walked: a row of thousands of
+          // entries is a hub row -- it shares a column with everything and groups with nothing -- and walking all of its lists
+          // is most of the run time on power-law graphs)
+          if ((fresh || n == 1) && (g.list_cap < 0 || (int64_t)resi.size() < 4 * (int64_t)g.list_cap)) {
             resi.push_back(c);
             prefetch(&g.meta[c]);
           }

@@ -388,7 +388,8 @@ int hcspmm_loi_reorder_variant(const int32_t* row_pointers_h, const int32_t* col
  * meant to speed up (Reddit-scale: 6.7 s on one host core against 0.4 s for 200 epochs).  Same group growth, profit,
  * tie rule and output order as reorder_plus_new_direct (LOI.cpp:660-805, :873-891); NOT the reference's permutation:
  *   list_cap : a walk of one column's row list reads at most this many rows behind the list's leading run of placed
- *              rows (0 = 64; < 0 = the whole list, as the reference does);
+ *              rows (0 = 64; < 0 = the whole list, as the reference does); of a member's columns the first 4 * list_cap
+ *              new ones are walked (hub rows);
  *   batch    : seeds grown concurrently per round against the placement state of the round's start; a row wanted by
  *              several groups of a round goes to the earliest seed (0 = clamp(num_nodes / 2048, 1, 2048); 1 = one seed
  *              at a time, as the reference does);

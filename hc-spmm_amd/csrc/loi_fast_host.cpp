@@ -509,13 +509,6 @@ extern "C" int hcspmm_loi_reorder_fast(const int32_t* rowptr, const int32_t* col
       bar.wait();
       if (n_seeds == 0) break;
       const double tb = t == 0 && dbg ? now() : 0;
-      if (T > 1) {
-        // the placement bitmap was written all over by the previous round's placements: fetch it back as ONE sequential
-        // sweep (N / 8 bytes, hardware-prefetched) instead of one cross-core miss per line in the middle of the growth
-        uint64_t sink = 0;
-        for (size_t i = 0; i < placed.size(); i += 8) sink += placed[i];
-        if (sink == 0x5eed5eed5eed5eedull) std::fprintf(stderr, " ");  // (keeps the sweep alive)
-      }
       // groups in flight per thread: as many as hide the misses of short groups, few enough that every thread gets seeds
       const int in_flight = (int)std::max<int64_t>(1, std::min<int64_t>(8, n_seeds / (2 * T)));
       // grow the round's groups against the frozen state, several in flight per thread; reserve every member for the

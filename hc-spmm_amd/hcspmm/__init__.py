@@ -250,6 +250,8 @@ def preprocess(column_index, row_pointers, num_nodes, num_edges, num_row_windows
     check(L.hcspmm_preprocess_host(_ptr(rp_h), _ptr(col_h), N, E, M, r, 0, _ptr(bp), _ptr(e2c), _ptr(e2r_h), _ptr(ht)))
     if not on_gpu:
         e2r = e2r_h
+    # the window products go up while the host builds the plan from them (pinned memory: asynchronous PCIe-rate copies)
+    up = [t.to(dev, non_blocking=True) for t in (bp, e2c, e2r, ht)]  # .to() is a no-op for the device-made e2r
     words = ctypes.c_int64(0)
     check(L.hcspmm_plan_words(_ptr(rp_h), N, E, _ptr(bp), _ptr(ht), ctypes.byref(_PLAN_PARAMS), ctypes.byref(words)))
     plan = torch.empty(max(int(words.value), Header.WORDS), dtype=torch.int32, pin_memory=on_gpu)
@@ -257,7 +259,7 @@ def preprocess(column_index, row_pointers, num_nodes, num_edges, num_row_windows
                               ctypes.byref(_PLAN_PARAMS), _ptr(plan), plan.numel()))
     h = Header.from_buffer_copy(plan[:Header.WORDS].numpy().tobytes())
     plan = plan[:h.total_words]  # hcspmm_plan_words sizes for the larger of the two layouts (column slices or none)
-    outs = [t.to(dev, non_blocking=True) for t in (bp, e2c, e2r, ht, plan)]  # .to() is a no-op for the device-made e2r
+    outs = up + [plan.to(dev, non_blocking=True)]
     _register(outs[4], h, row_pointers, column_index)
     col_nzr = torch.zeros(1, dtype=torch.int32, device=dev)
     return [outs[0], outs[1], outs[2], outs[3], outs[4], col_nzr]

@@ -287,6 +287,8 @@ std::vector<torch::Tensor> preprocess(torch::Tensor edgeList_tensor, torch::Tens
   check_rc(hcspmm_preprocess_host(rp.data_ptr<int>(), iptr(col), N, E, M, g_rule, 0, mptr(bp), mptr(e2c),
                                   dev.is_cuda() ? nullptr : mptr(e2r), mptr(ht)),
            "preprocess");
+  // the window products go up while the host builds the plan from them (pinned memory: asynchronous PCIe-rate copies)
+  auto bp_d = bp.to(dev, true), e2c_d = e2c.to(dev, true), ht_d = ht.to(dev, true);
   int64_t words = 0;
   check_rc(hcspmm_plan_words(rp.data_ptr<int>(), N, E, iptr(bp), iptr(ht), &g_params, &words), "preprocess(plan size)");
   auto plan = torch::empty({std::max<int64_t>(words, HCSPMM_PLAN_HEADER_WORDS)}, hopts);
@@ -299,7 +301,7 @@ std::vector<torch::Tensor> preprocess(torch::Tensor edgeList_tensor, torch::Tens
   auto plan_d = plan.to(dev, /*non_blocking=*/true);
   if (plan_d.is_cuda()) remember(plan_d, h, &nodePointer_tensor, &edgeList_tensor);
   auto col_nzr = torch::zeros({1}, opts).to(dev);  // stays the reference's placeholder (K.cu:405)
-  return {bp.to(dev, true), e2c.to(dev, true), e2r.to(dev), ht.to(dev, true), plan_d, col_nzr};
+  return {bp_d, e2c_d, e2r.to(dev), ht_d, plan_d, col_nzr};
 }
 
 #define HCSPMM_GRAPH_PARAMS                                                                                   \

@@ -38,11 +38,14 @@
 // All section offsets are multiples of 4 words, the compact sections' of 64.  With slices the sections are sized
 // by upper bounds that do not depend on the column ids (hcspmm_plan_words has none): the header holds the real counts.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -131,9 +134,76 @@ struct Layout {
           off_sparse_windows = 0, off_slice_table = 0, off_slice_tasks = 0, total = 0;
 };
 
-// Runs fn(t) for t in [0, T) on T threads (T == 1: inline).
+// The workers of ONE hcspmm_plan_build / hcspmm_plan_words call: started once, handed the call's passes one after the other (a
+// pass used to start and join its own threads: eight start-ups of 16 threads were a quarter of the Reddit-scale plan build).
+// Call-local -- created and joined inside the entry point, reached by the passes through a thread-local pointer -- so the library
+// still keeps no state between calls.  Workers spin briefly, then sleep on a condition variable.
+class PassPool {
+ public:
+  explicit PassPool(int T) : T_(T) {
+    for (int t = 1; t < T_; ++t) th_.emplace_back([this, t] { work(t); });
+  }
+  ~PassPool() {
+    fn_ = nullptr;
+    post();
+    for (auto& x : th_) x.join();
+  }
+  int size() const { return T_; }
+  template <typename F> void run(F& fn) {
+    fn_ = [](void* f, int t) { (*static_cast<F*>(f))(t); };
+    arg_ = &fn;
+    done_.store(0, std::memory_order_relaxed);
+    post();
+    fn(0);
+    for (int spin = 0; done_.load(std::memory_order_acquire) != T_ - 1; ++spin)
+      if (spin > 256) std::this_thread::yield();
+  }
+
+ private:
+  void post() {  // the next pass (or the end) is there: spinning workers see the counter, sleeping ones the notification
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      gen_.fetch_add(1, std::memory_order_release);
+    }
+    cv_.notify_all();
+  }
+  void work(int t) {
+    uint64_t seen = 0;
+    for (;;) {
+      // a short spin (the serial sections between passes are tens of microseconds), then sleep: a worker that kept spinning
+      // would burn the CPU share the caller's serial section needs on a busy host
+      for (int spin = 0; spin < 4000 && gen_.load(std::memory_order_acquire) == seen; ++spin) {
+      }
+      if (gen_.load(std::memory_order_acquire) == seen) {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
+      }
+      ++seen;
+      if (!fn_) return;
+      fn_(arg_, t);
+      done_.fetch_add(1, std::memory_order_release);
+    }
+  }
+  const int T_;
+  std::vector<std::thread> th_;
+  void (*fn_)(void*, int) = nullptr;
+  void* arg_ = nullptr;
+  std::atomic<uint64_t> gen_{0};
+  std::atomic<int> done_{0};
+  std::mutex m_;
+  std::condition_variable cv_;
+};
+thread_local PassPool* tl_pool = nullptr;
+struct PoolScope {  // the pool of an entry point, for its duration
+  PassPool pool;
+  explicit PoolScope(int T) : pool(T) { tl_pool = T > 1 ? &pool : nullptr; }
+  ~PoolScope() { tl_pool = nullptr; }
+};
+
+// Runs fn(t) for t in [0, T) on T threads (T == 1: inline): on the entry point's pool when it has one of that size, else on threads of its own.
 template <typename F> void parallel_for(int T, F fn) {
   if (T <= 1) { fn(0); return; }
+  if (tl_pool && tl_pool->size() == T) { tl_pool->run(fn); return; }
   std::vector<std::thread> th;
   th.reserve((size_t)T);
   for (int t = 0; t < T; ++t) th.emplace_back(fn, t);
@@ -226,6 +296,7 @@ extern "C" int hcspmm_plan_words(const int32_t* rowptr, int64_t N, int64_t E, co
   // whether rows get sliced is decided where the column ids are known (hcspmm_plan_build): unless the parameters
   // settle it, size the tensor for either outcome
   const Resolved rp = resolve(params);
+  PoolScope scope(plan_threads((N + HCSPMM_BLK_H - 1) / HCSPMM_BLK_H));
   Layout L, Ls;
   int rc = HCSPMM_OK;
   int64_t total = 0;
@@ -288,6 +359,7 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
   if (N > INT32_MAX - 16 || E > INT32_MAX) return HCSPMM_ERANGE;
   if (M <= 0) M = N;
   if (M > INT32_MAX) return HCSPMM_ERANGE;
+  PoolScope scope(plan_threads((N + HCSPMM_BLK_H - 1) / HCSPMM_BLK_H));
   // HCSPMM_PLAN_DEBUG=1: the phases' wall times on stderr
   static const bool dbg = std::getenv("HCSPMM_PLAN_DEBUG") != nullptr;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };

@@ -8,9 +8,10 @@ vp=ctypes.c_void_p; i64=ctypes.c_int64
 def P(a): return vp(a.ctypes.data) if a is not None and a.size else vp(0)
 rng=np.random.default_rng(0)
 n_ok=0
-for trial in range(12 if TSAN else 40):
+for trial in range(16 if TSAN else 40):
     kind=trial%5
     N=int(rng.choice([1,15,16,17,50,64,333,1000,5000,70000]))
+    if TSAN and trial < 5: N = 70000  # large enough for the threaded paths (plan pool from 4096 windows, relaxed LOI from 4096 rows)
     if kind==0: rp,col=graphs.powerlaw_graph(max(N,8),max(N,8)*int(rng.integers(1,20)),seed=trial,max_degree_frac=float(rng.choice([0.02,0.9])))
     elif kind==1: rp,col=graphs.uniform_graph(max(N,4),max(N,4)*int(rng.integers(0,8))+1,seed=trial)
     elif kind==2: rp,col=graphs.planted_dense_graph_fast(max(N,32),seed=trial,dense_fraction=0.5,k_cols=int(rng.choice([4,20,41,64,130])),fill=0.5,sparse_degree=3)
@@ -18,7 +19,7 @@ for trial in range(12 if TSAN else 40):
     else:
         n=max(N,1); rp,col=np.zeros(n+1,np.int32),np.zeros(0,np.int32)
     N=len(rp)-1; E=len(col); W=(N+15)//16
-    for rule in (() if TSAN else (0,2,4)):
+    for rule in (((3,) if N >= 60000 else ()) if TSAN else (0,2,4)):
         bp=np.zeros(W,np.int32); ht=np.zeros(W,np.int32); e2c=np.zeros(E,np.int32); e2r=np.zeros(E,np.int32)
         rc=L.hcspmm_preprocess_host(P(rp),P(col),i64(N),i64(E),i64(N),rule,int(rng.choice([0,1,3])),P(bp),P(e2c),P(e2r),P(ht)); assert rc==0,rc
         for force in (None,1):

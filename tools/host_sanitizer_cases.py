@@ -51,6 +51,11 @@ for trial in range(16 if TSAN else 40):
         rp2=np.zeros(N+1,np.int32); col2=np.zeros(E,np.int32)
         L.hcspmm_loi_reorder_variant(P(rp),P(col),i64(N),i64(E),0,P(perm),P(gs),ctypes.byref(ng))
         rc=L.hcspmm_apply_permutation(P(rp),P(col),i64(N),i64(E),P(perm),P(rp2),P(col2)); assert rc==0
+    if N >= 50 and E > 0 and not TSAN:  # a row pointer that decreases, or points past the entries, in the middle of the array: refused by the window pass before any column is read
+        for pos, val in ((N // 2, int(rp[N // 2 + 1]) + 5), (N // 3, E + 1000), (N // 3, -4)):
+            rb = rp.copy(); rb[pos] = val
+            if np.all(np.diff(rb) >= 0) and rb[pos] <= E and rb[pos] >= 0: continue
+            rc=L.hcspmm_preprocess_host(P(rb),P(col),i64(N),i64(E),i64(N),3,int(rng.choice([0,1,3])),P(bp),P(e2c),P(e2r),P(ht)); assert rc==-1,rc
     if N >= 50 and E > 0:  # malformed row pointers must be refused before any column is read (all LOI variants, plan, preprocess)
         for bad0, badN in ((1, rp[-1]), (0, rp[-1] + 7), (0, max(rp[-1] - 1, 0)), (-3, rp[-1])):
             rb = rp.copy(); rb[0] = bad0; rb[-1] = badN

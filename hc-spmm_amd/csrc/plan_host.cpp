@@ -500,13 +500,21 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
     }
   };
   parallel_for(T, [&](int t) {
+    // counters private to the thread (its own stack and heap blocks) until the end: the Counts records of neighbouring threads share
+    // cache lines, and a counter bumped per row there cost the RD-sized graph several milliseconds of line ping-pong
+    std::vector<int64_t> cls((size_t)n_cls, 0), slice_cls((size_t)S * (size_t)n_cls, 0);
+    int64_t n_fix = 0, n_slots = 0, n_dense = 0, n_sparse_w = 0;
+    walk(t, true, [&](int32_t, int32_t, int32_t len, int32_t) { cls[(size_t)length_class(len)]++; },
+         [&](int64_t, int64_t segs) { n_fix++; n_slots += segs; return (int64_t)0; },
+         [&](int64_t) { n_dense++; }, [&](int64_t) { n_sparse_w++; },
+         [&](int sl, int32_t, int32_t, int32_t len, int32_t) { slice_cls[(size_t)sl * (size_t)n_cls + (size_t)length_class(len)]++; });
     Counts& c = cnt[(size_t)t];
-    c.cls.assign((size_t)n_cls, 0);
-    c.slice_cls.assign((size_t)S * (size_t)n_cls, 0);
-    walk(t, true, [&](int32_t, int32_t, int32_t len, int32_t) { c.cls[(size_t)length_class(len)]++; },
-         [&](int64_t, int64_t segs) { c.n_fix++; c.n_slots += segs; return (int64_t)0; },
-         [&](int64_t) { c.n_dense++; }, [&](int64_t) { c.n_sparse_w++; },
-         [&](int sl, int32_t, int32_t, int32_t len, int32_t) { c.slice_cls[(size_t)sl * (size_t)n_cls + (size_t)length_class(len)]++; });
+    c.cls.swap(cls);
+    c.slice_cls.swap(slice_cls);
+    c.n_fix = n_fix;
+    c.n_slots = n_slots;
+    c.n_dense = n_dense;
+    c.n_sparse_w = n_sparse_w;
   });
   // class starts (bucket 0 = longest class), then per-thread offsets inside each class, in range order
   std::vector<int64_t> start((size_t)n_cls + 1, 0);
@@ -580,8 +588,8 @@ extern "C" int hcspmm_plan_build(const int32_t* rowptr, const int32_t* col, int6
   int32_t* sparse_w = plan + L.off_sparse_windows;
   int32_t* sout = plan + L.off_slice_tasks;
   parallel_for(T, [&](int t) {
-    std::vector<int64_t>& p = pos[(size_t)t];
-    std::vector<int64_t>& sp = spos[(size_t)t];
+    std::vector<int64_t> p = pos[(size_t)t];    // thread-private copies: the cursors are bumped per task, and the per-thread vectors
+    std::vector<int64_t> sp = spos[(size_t)t];  // the caller allocated sit next to each other in memory
     int64_t n_fix = fix_at[(size_t)t], slot = slot_at[(size_t)t], nd = dense_at[(size_t)t], nsw = sparse_w_at[(size_t)t];
     walk(t, false,
          [&](int32_t row, int32_t e0, int32_t len, int32_t slot_id) {

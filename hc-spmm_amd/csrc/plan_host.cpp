@@ -212,6 +212,8 @@ template <typename F> void parallel_for(int T, F fn) {
 
 // host threads for the plan passes: they are memory-bound and start their threads several times over, so beyond 16
 // threads they get slower (3.6 / 3.7 / 5.6 / 10 / 20 ms at 8 / 16 / 32 / 64 / 128 threads on the Reddit-scale graph)
+// (measured again with the call-local pool and thread-private counters: 32 / 64 threads still lose -- Reddit-scale plan build 3.5 ms at 16,
+// 16-17 ms at 32 / 64: the per-thread boundary histograms and the pool's hand-overs grow with the thread count)
 int plan_threads(int64_t W) { return W < 4096 ? 1 : std::min(hcspmm::host_threads(), 16); }
 
 int compute_layout(const int32_t* rowptr, int64_t N, const int32_t* bp, const int32_t* ht, const Resolved& rp,
@@ -320,7 +322,7 @@ static inline int length_class(int32_t len) { return len <= 1 ? (len > 0 ? 1 : 0
 // fingerprint of (rowptr, col) + range check of col against [0, M): one parallel pass over both arrays
 static int fingerprint_and_check(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, int64_t M, uint64_t* out) {
   if (rowptr[0] != 0 || rowptr[N] != E) return HCSPMM_EINVAL;
-  const int T = (N + E < (1 << 18)) ? 1 : std::min(hcspmm::host_threads(), 16);
+  const int T = (N + E < (1 << 18)) ? 1 : plan_threads(1 << 20);  // (the entry point's pool when it has one)
   std::vector<uint64_t> part((size_t)T, 0);
   std::vector<int> bad((size_t)T, 0);
   parallel_for(T, [&](int t) {

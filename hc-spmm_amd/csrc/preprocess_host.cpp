@@ -9,6 +9,7 @@
 // per window the sorted unique column list is built once and every row is ranked against it with
 // a linear merge (rows are ascending, so no per-entry binary search is needed).
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <thread>
 #include <vector>
@@ -60,10 +61,13 @@ inline int classify(int32_t size, uint32_t nnz, int32_t num, int rule) {
 // The row pointers are checked here too, window by window and before a single column id of the window is read: inside [0, E] and
 // never decreasing (the caller has checked rowptr[0] == 0 and rowptr[N] == E) -- as a sequential loop ahead of the threads this was
 // 2 ms of the RD-sized graph's 7.
+struct Scratch {  // a thread's buffers, kept across the chunks of windows it takes
+  std::vector<int32_t> uniq, buf_a, buf_b;
+};
 void process_windows(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, int64_t M, int64_t w_begin, int64_t w_end,
                      int rule, int32_t* blockPartition, int32_t* edgeToColumn, int32_t* edgeToRow, int32_t* hybrid_type,
-                     int* bad) {
-  std::vector<int32_t> uniq, buf_a, buf_b;
+                     int* bad, Scratch& scratch) {
+  std::vector<int32_t>&uniq = scratch.uniq, &buf_a = scratch.buf_a, &buf_b = scratch.buf_b;
   for (int64_t w = w_begin; w < w_end; ++w) {
     const int64_t r0 = w * HCSPMM_BLK_H, r1 = std::min<int64_t>(r0 + HCSPMM_BLK_H, N);
     const int64_t lo = rowptr[r0], hi = rowptr[r1];
@@ -165,24 +169,37 @@ extern "C" int hcspmm_preprocess_host(const int32_t* rowptr, const int32_t* col,
   if (W < 4 * T || E < (1 << 16)) T = 1;
   if (T == 1) {
     int bad = 0;
-    process_windows(rowptr, col, N, E, M, 0, W, rule, blockPartition, edgeToColumn, edgeToRow, hybrid_type, &bad);
+    Scratch scratch;
+    process_windows(rowptr, col, N, E, M, 0, W, rule, blockPartition, edgeToColumn, edgeToRow, hybrid_type, &bad, scratch);
     return bad ? HCSPMM_EINVAL : HCSPMM_OK;
   }
-  // contiguous window ranges with ~equal (entries + windows) each
-  std::vector<int64_t> cut(T + 1, W);
+  // Chunks of consecutive windows with about equal (entries + windows) each, many more than threads, handed out by an atomic counter:
+  // the cost of a window is not linear in its entries (a hub window's merge passes miss the L1), and fixed ranges left the launch
+  // waiting for its slowest thread (12 ms on 16 threads where 64 took 4.5).  Every output is per window: the result does not depend
+  // on who takes which chunk.
+  const int n_chunks = (int)std::min<int64_t>(W, (int64_t)T * 32);
+  std::vector<int64_t> cut((size_t)n_chunks + 1, W);
   cut[0] = 0;
   const double total = (double)E + (double)W;
   int64_t w = 0;
-  for (int t = 1; t < T; ++t) {
-    const double target = total * t / T;
+  for (int c = 1; c < n_chunks; ++c) {
+    const double target = total * c / n_chunks;
     while (w < W && (double)rowptr[std::min<int64_t>(w * HCSPMM_BLK_H, N)] + (double)w < target) ++w;
-    cut[t] = w;
+    cut[(size_t)c] = w;
   }
   std::vector<std::thread> th;
   std::vector<int> bad((size_t)T, 0);
+  std::atomic<int> next{0};
   for (int t = 0; t < T; ++t)
-    th.emplace_back(process_windows, rowptr, col, N, E, M, cut[t], cut[t + 1], rule, blockPartition, edgeToColumn, edgeToRow,
-                    hybrid_type, &bad[(size_t)t]);
+    th.emplace_back([&, t] {
+      Scratch scratch;
+      for (;;) {
+        const int c = next.fetch_add(1, std::memory_order_relaxed);
+        if (c >= n_chunks || bad[(size_t)t]) break;
+        process_windows(rowptr, col, N, E, M, cut[(size_t)c], cut[(size_t)c + 1], rule, blockPartition, edgeToColumn, edgeToRow, hybrid_type,
+                        &bad[(size_t)t], scratch);
+      }
+    });
   for (auto& x : th) x.join();
   for (int t = 0; t < T; ++t)
     if (bad[(size_t)t]) return HCSPMM_EINVAL;

@@ -406,7 +406,7 @@ def cpu_baseline(rp, col, X_host, D, n_cols, budget_s=20.0):
 
 # ------------------------------------------------------------------------------------------------
 def run_case(fe, dev, workload, D, rp, col, n_local, world, rank, vworld, steps, warmup, dtype_name="f32", rule=0,
-             no_plan=False, n_gather_panels=0, dist=None, prep_runs=2, keep_op=False):
+             no_plan=False, n_gather_panels=0, dist=None, prep_runs=3, keep_op=False):
     """Preprocess + `steps` timed steps of one workload on this rank; returns the measurements (no printing)."""
     import torch
     from hcspmm.sharded import ShardedGraph, ShardedSpMM
@@ -419,7 +419,8 @@ def run_case(fe, dev, workload, D, rp, col, n_local, world, rank, vworld, steps,
     rp_d, col_d = torch.from_numpy(rp).to(dev), torch.from_numpy(col).to(dev)
     W = (n_local + 15) // 16
     prep = []
-    for _ in range(prep_runs):  # cold (first touch: pinned staging buffers, code objects, allocator growth), then warm
+    for _ in range(prep_runs):  # cold (first touch: pinned staging buffers, code objects, allocator growth), then warm (the faster of two:
+        # the host passes are a few milliseconds on up to 64 threads of a shared host, and one descheduled thread doubles a single sample)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         bp, e2c, e2r, ht, row_nzr, col_nzr = fe.preprocess(col_d, rp_d, n_local, E, W, rule, n_cols)
@@ -495,7 +496,7 @@ def run_case(fe, dev, workload, D, rp, col, n_local, world, rank, vworld, steps,
     flags[col] = True
     kept = {"op": op} if keep_op else {}
     return {**kept, "workload": workload, "D": D, "N": n_local, "E": E, "n_cols": n_cols, "elem": elem, "header": header,
-            "elapsed": elapsed, "steps": steps, "kernel_ms": kern_ms, "prep_cold_ms": prep[0], "prep_warm_ms": prep[-1],
+            "elapsed": elapsed, "steps": steps, "kernel_ms": kern_ms, "prep_cold_ms": prep[0], "prep_warm_ms": min(prep[1:]) if len(prep) > 1 else prep[0],
             "n_gather_panels": n_gather_panels, "cols_referenced": int(flags.sum()), "x_rows": n_cols,
             "hip_graph_ms_per_step": graph_ms}
 

@@ -533,8 +533,10 @@ extern "C" int hcspmm_loi_reorder_fast(const int32_t* rowptr, const int32_t* col
         for (Grower& w : gr) {
           if (w.stage == Grower::kIdle) continue;
           if (w.advance(g)) continue;
-          sizes[(size_t)(base + w.index)] = w.n;
-          std::memcpy(&cur_members[(size_t)w.index * 16], w.out, sizeof(int32_t) * (size_t)w.n);
+          // (all 16 slots, the unused ones -1: the placement pass counts them, so no per-group size is written here -- neighbouring
+          // groups are completed by different threads, and sixteen of their sizes would share a cache line)
+          for (int k = w.n; k < 16; ++k) w.out[k] = -1;
+          std::memcpy(&cur_members[(size_t)w.index * 16], w.out, sizeof(int32_t) * 16);
           if (n_seeds > 1) {
             const int32_t id = (int32_t)(base + w.index);
             for (int k = 0; k < w.n; ++k) {
@@ -554,7 +556,8 @@ extern "C" int hcspmm_loi_reorder_fast(const int32_t* rowptr, const int32_t* col
       const int64_t per = (n_seeds + T - 1) / T;
       for (int64_t i = t * per; i < std::min(n_seeds, (t + 1) * per); ++i) {
         int32_t* out = &cur_members[(size_t)i * 16];
-        const int n = sizes[(size_t)(base + i)];
+        int n = 0;
+        while (n < 16 && out[n] >= 0) ++n;
         int keep = 0;
         for (int k = 0; k < n; ++k) {
           const int32_t v = out[k];

@@ -124,17 +124,21 @@ void process_windows(const int32_t* rowptr, const int32_t* col, int64_t N, int64
         runs = out_runs;
         std::swap(src, dst);
       }
-      uniq.assign(src, src + m);
+      uniq.resize(m);
+      uniq.erase(std::unique_copy(src, src + m, uniq.begin()), uniq.end());  // (de-duplicated on the way out of the merge buffer)
     }
-    uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+    if (!rows_ascending) uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
     const int32_t size = (int32_t)uniq.size() - 1;                      // K.cu:256-257
     const int32_t num = (size + HCSPMM_BLK_W) / HCSPMM_BLK_W;           // K.cu:258
     blockPartition[w] = num;
     hybrid_type[w] = classify(size, (uint32_t)(hi - lo), num, rule);
     for (int64_t r = r0; r < r1; ++r) {
       const int64_t a = rowptr[r], b = rowptr[r + 1];
-      bool ascending = true;
-      for (int64_t e = a + 1; e < b; ++e) ascending &= col[e - 1] <= col[e];
+      bool ascending = rows_ascending;  // (checked once for the whole window above)
+      if (!ascending) {
+        ascending = true;
+        for (int64_t e = a + 1; e < b; ++e) ascending &= col[e - 1] <= col[e];
+      }
       if (ascending) {  // merge walk: both sequences ascending
         size_t p = 0;
         for (int64_t e = a; e < b; ++e) {

@@ -617,6 +617,34 @@ def test_apply_permutation_parallel_path_matches_scipy():
     assert np.array_equal(rp2.numpy(), B.indptr) and np.array_equal(col2.numpy(), B.indices)
 
 
+def test_loi_program_writes_the_reference_order_file(tmp_path, capsys):
+    """hc-spmm_amd/LOI.py, the counterpart of LOI.cpp's main (LOI.cpp:807-896): dataset text file in, reorder_direct.txt out -- one old
+    vertex id per line in the reference's order -- plus the relabelled graph on request."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("hc_spmm_loi_program", os.path.join(ROOT, "hc-spmm_amd", "LOI.py"))
+    prog = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(prog)
+    g = np.load(os.path.join(GOLD, "loi_powerlaw_sym_600.npz"))
+    rp, col = g["row_pointers"], g["column_index"]
+    src = str(tmp_path / "graph.txt")
+    graphs.write_coo_text(src, rp, col)
+    out, moved = str(tmp_path / "reorder_direct.txt"), str(tmp_path / "graph_loi.txt")
+    prog.main([src, "--out", out, "--apply", moved])
+    printed = capsys.readouterr().out.split("\n")
+    assert printed[0].startswith("All time: ") and int(printed[1]) == int((g["group_sizes"] == 16).sum())
+    order = np.loadtxt(out, dtype=np.int64)
+    assert np.array_equal(order, g["order"])  # (every vertex of this graph has an entry, so the text file carries all 600)
+    rp2, col2 = prog.read_csr(moved)
+    want_rp, want_col = hcspmm.apply_permutation(_t(rp), _t(col), _t(order.astype(np.int32)))
+    # (the reorder puts the rows without entries last, and a text file of entries cannot name trailing empty rows: the reader sees the
+    # graph up to its last non-empty row)
+    k = len(rp2)
+    assert np.array_equal(rp2, want_rp.numpy()[:k]) and bool((want_rp.numpy()[k - 1:] == len(col)).all()) and np.array_equal(col2, want_col.numpy())
+    # the relaxed variant through the same program
+    prog.main([src, "--out", out, "--variant", "fast"])
+    assert sorted(np.loadtxt(out, dtype=np.int64).tolist()) == list(range(len(rp) - 1))
+
+
 def test_apply_permutation_is_a_graph_isomorphism():
     import scipy.sparse as sp
     rp, col = graphs.powerlaw_graph(700, 5000, seed=6)

@@ -24,6 +24,9 @@
 extern "C" {
 #endif
 
+/* 3 = the signatures below.  Entry points ADDED since 3 was introduced leave it unchanged (a consumer built against an older header keeps
+ * working): hcspmm_loi_reorder_fast, hcspmm_dense_update (round 4).  HCSPMM_RULE_MI355X as the front-ends' default classifier is a front-end
+ * matter: every C entry point that classifies takes its rule as an argument. */
 #define HCSPMM_ABI_VERSION 3
 
 /* Row-window geometry: hybrid_kernel/config.h:4-5 (BLK_H 16, BLK_W 8). */

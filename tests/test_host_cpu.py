@@ -569,6 +569,30 @@ def test_fast_loi_is_a_permutation_independent_of_the_thread_count():
         assert torch.equal(a, b) and np.array_equal(np.sort(a.numpy()), np.arange(N))
 
 
+def test_fast_loi_parameter_corners():
+    """Tiny graphs, more seeds per round than vertices, caps of 1, one seed at a time: always a permutation that covers every non-empty
+    row with a group, the same for any thread count, and the exact order when both relaxations are off."""
+    rng = np.random.default_rng(0)
+    for trial in range(16):
+        N = int(rng.choice([1, 2, 17, 100, 999, 4096, 6000]))
+        if trial % 4 == 0:
+            rp, col = graphs.powerlaw_graph(max(N, 8), max(N, 8) * int(rng.integers(1, 12)), seed=trial, max_degree_frac=float(rng.choice([0.02, 0.9])))
+        elif trial % 4 == 1:
+            rp, col = graphs.uniform_graph(max(N, 4), max(N, 4) * int(rng.integers(0, 6)) + 1, seed=trial)
+        elif trial % 4 == 2:
+            rp, col = graphs.molecule_graph(max(N, 50), seed=trial)
+        else:
+            rp, col = graphs.community_graph(max(N, 64), max(N, 64) * 2, seed=trial)[:2]
+        n = len(rp) - 1
+        for kw in (dict(), dict(batch=int(rng.integers(1, 50)), list_cap=int(rng.choice([-1, 1, 3, 64]))), dict(batch=n + 5), dict(batch=1, list_cap=-1)):
+            a, b = (hcspmm.loi_reorder(_t(rp), _t(col), variant="fast", threads=t, **kw) for t in (1, 3))
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (trial, kw)
+            assert np.array_equal(np.sort(a[0].numpy()), np.arange(n)) and int(a[1].sum()) == int((np.diff(rp) > 0).sum()), (trial, kw)
+            if kw == dict(batch=1, list_cap=-1):
+                pe, se = hcspmm.loi_reorder(_t(rp), _t(col))
+                assert torch.equal(pe, a[0]) and torch.equal(se, a[1]), trial
+
+
 def test_fast_loi_recovers_planted_communities():
     """community_graph hides groups of 8-40 rows sharing a column pool behind shuffled vertex ids; after the relaxed reorder most
     16-row windows must again come from one or two planted groups, about as many as after the exact reorder."""
